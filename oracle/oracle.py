@@ -1,0 +1,285 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+
+All arrays are C-contiguous float32 in the reference's NCHW layout.  The
+model-level functions at the bottom restate the reference forward passes
+(core/models/model.py:147-175, core/arch/RepRFN.py:327-339) on top of the
+per-operator C functions, taking a reference-format state dict
+(name -> numpy array, OIHW weights).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i = ctypes.c_int
+
+
+def build():
+    """Compile liboracle.so in place (gcc only; used by __graft_entry__.build())."""
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_f32p) if a is not None else None
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def set_threads(n):
+    os.environ["OMP_NUM_THREADS"] = str(int(n))
+
+
+# ---------------------------------------------------------------------------
+# operators
+# ---------------------------------------------------------------------------
+def conv2d(x, w, b=None, stride=1, padding=0, groups=1, act=0, slope=0.0):
+    x, w = _c(x), _c(w)
+    b = _c(b) if b is not None else None
+    N, Cin, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    Ho = (H + 2 * ph - kh) // sh + 1
+    Wo = (W + 2 * pw - kw) // sw + 1
+    y = np.empty((N, Cout, Ho, Wo), np.float32)
+    lib().orc_conv2d_fwd(_p(x), _p(w), _p(b), _p(y), _i(N), _i(Cin), _i(H), _i(W), _i(Cout),
+                         _i(kh), _i(kw), _i(sh), _i(sw), _i(ph), _i(pw), _i(groups), _i(act),
+                         ctypes.c_float(slope))
+    return y
+
+
+def conv2d_bwd_input(dy, w, in_shape, stride=1, padding=0, groups=1):
+    dy, w = _c(dy), _c(w)
+    N, Cin, H, W = in_shape
+    Cout, _, kh, kw = w.shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    dx = np.empty(in_shape, np.float32)
+    lib().orc_conv2d_bwd_input(_p(dy), _p(w), _p(dx), _i(N), _i(Cin), _i(H), _i(W), _i(Cout),
+                               _i(kh), _i(kw), _i(sh), _i(sw), _i(ph), _i(pw), _i(groups))
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, w_shape, stride=1, padding=0, groups=1, with_bias=True):
+    x, dy = _c(x), _c(dy)
+    N, Cin, H, W = x.shape
+    Cout, _, kh, kw = w_shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    dw = np.empty(w_shape, np.float32)
+    db = np.empty((Cout,), np.float32) if with_bias else None
+    lib().orc_conv2d_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), _i(N), _i(Cin), _i(H), _i(W),
+                                _i(Cout), _i(kh), _i(kw), _i(sh), _i(sw), _i(ph), _i(pw), _i(groups))
+    return dw, db
+
+
+def make_coord(h, w):
+    out = np.empty((1, 2, h, w), np.float32)
+    lib().orc_make_coord(_p(out), _i(h), _i(w))
+    return out
+
+
+_MODES = {"bilinear": 0, "nearest": 1}
+
+
+def grid_sample(inp, grid, mode="bilinear", align_corners=False):
+    inp, grid = _c(inp), _c(grid)
+    N, C, H, W = inp.shape
+    _, Ho, Wo, _ = grid.shape
+    out = np.empty((N, C, Ho, Wo), np.float32)
+    lib().orc_grid_sample(_p(inp), _p(grid), _p(out), _i(N), _i(C), _i(H), _i(W), _i(Ho), _i(Wo),
+                          _i(_MODES[mode]), _i(int(align_corners)))
+    return out
+
+
+def grid_sample_bwd(inp, grid, dout, align_corners=False, need_dgrid=True):
+    inp, grid, dout = _c(inp), _c(grid), _c(dout)
+    N, C, H, W = inp.shape
+    _, Ho, Wo, _ = grid.shape
+    din = np.zeros_like(inp)
+    dgrid = np.empty_like(grid) if need_dgrid else None
+    lib().orc_grid_sample_bwd(_p(inp), _p(grid), _p(dout), _p(din), _p(dgrid), _i(N), _i(C), _i(H),
+                              _i(W), _i(Ho), _i(Wo), _i(int(align_corners)))
+    return din, dgrid
+
+
+def upsample_grid_bilinear(inp, th, tw):
+    inp = _c(inp)
+    N, C, sh, sw = inp.shape
+    out = np.empty((N, C, th, tw), np.float32)
+    lib().orc_upsample_grid_bilinear(_p(inp), _p(out), _i(N), _i(C), _i(sh), _i(sw), _i(th), _i(tw))
+    return out
+
+
+def warp_grid(motion):
+    motion = _c(motion)
+    N, _, h, w = motion.shape
+    grid = np.empty((N, h, w, 2), np.float32)
+    lib().orc_warp_grid(_p(motion), _p(grid), _i(N), _i(h), _i(w))
+    return grid
+
+
+def backward_warp(frame, motion, mode="nearest", align_corners=True):
+    frame, motion = _c(frame), _c(motion)
+    N, C, h, w = frame.shape
+    out = np.empty_like(frame)
+    lib().orc_backward_warp(_p(frame), _p(motion), _p(out), _i(N), _i(C), _i(h), _i(w),
+                            _i(_MODES[mode]), _i(int(align_corners)))
+    return out
+
+
+def rel_coord(th, tw, sh, sw):
+    out = np.empty((1, 2, th, tw), np.float32)
+    lib().orc_rel_coord(_p(out), _i(th), _i(tw), _i(sh), _i(sw))
+    return out
+
+
+def pixel_shuffle(x, r):
+    x = _c(x)
+    N, Crr, H, W = x.shape
+    C = Crr // (r * r)
+    out = np.empty((N, C, H * r, W * r), np.float32)
+    lib().orc_pixel_shuffle(_p(x), _p(out), _i(N), _i(C), _i(H), _i(W), _i(r))
+    return out
+
+
+def pixel_unshuffle(x, r):
+    x = _c(x)
+    N, C, Hr, Wr = x.shape
+    H, W = Hr // r, Wr // r
+    out = np.empty((N, C * r * r, H, W), np.float32)
+    lib().orc_pixel_unshuffle(_p(x), _p(out), _i(N), _i(C), _i(H), _i(W), _i(r))
+    return out
+
+
+def nearest_down(x, scale_factor):
+    x = _c(x)
+    N, C, H, W = x.shape
+    Ho, Wo = int(np.floor(H * scale_factor)), int(np.floor(W * scale_factor))
+    out = np.empty((N, C, Ho, Wo), np.float32)
+    lib().orc_nearest_down(_p(x), _p(out), _i(N * C), _i(H), _i(W), ctypes.c_double(scale_factor),
+                           _i(Ho), _i(Wo))
+    return out
+
+
+def layernorm_cf(x, weight, bias, eps=1e-6):
+    x, weight, bias = _c(x), _c(weight), _c(bias)
+    N, C, H, W = x.shape
+    y = np.empty_like(x)
+    lib().orc_layernorm_cf(_p(x), _p(weight), _p(bias), _p(y), _i(N), _i(C), _i(H * W),
+                           ctypes.c_float(eps))
+    return y
+
+
+def max_pool2d(x, k, s):
+    x = _c(x)
+    N, C, H, W = x.shape
+    Ho, Wo = (H - k) // s + 1, (W - k) // s + 1
+    out = np.empty((N, C, Ho, Wo), np.float32)
+    lib().orc_max_pool2d(_p(x), _p(out), _i(N * C), _i(H), _i(W), _i(k), _i(s))
+    return out
+
+
+def resize_bilinear(x, Ho, Wo):
+    x = _c(x)
+    N, C, H, W = x.shape
+    out = np.empty((N, C, Ho, Wo), np.float32)
+    lib().orc_resize_bilinear(_p(x), _p(out), _i(N * C), _i(H), _i(W), _i(Ho), _i(Wo))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# model-level restatements
+# ---------------------------------------------------------------------------
+def supersampler_forward(sd, lr_frames, hr_buffers, return_intermediates=False):
+    """core/models/model.py:147-175 on a reference state dict `sd`.
+
+    lr_frames (B,L,3,sh,sw), hr_buffers (B,L,10,th,tw) -> sr_frames (B,3,th,tw).
+    """
+    def ca(x, key, act=1):  # ConvActivation, model.py:10-14
+        return conv2d(x, sd[key + ".weight"], sd[key + ".bias"], 1, 1, act=act)
+
+    lr = _c(lr_frames[:, -1])
+    hb = _c(hr_buffers[:, -1])
+    th, tw = hb.shape[-2:]
+    # frame_extractor, model.py:50-58 (require_first=False)
+    f = lr
+    for i in range(3):
+        f = ca(f, f"frame_extractor.blks.{i}.0")
+    fmap_curr = f
+    up = upsample_grid_bilinear(fmap_curr, th, tw)  # model.py:153,162
+    # gbuffers_extractor, model.py:61-79
+    g = hb
+    for i in range(3):
+        g = ca(g, f"gbuffers_extractor.blks.{2 * i}.0")
+        r = ca(g, f"gbuffers_extractor.blks.{2 * i + 1}.0.0")
+        r = ca(r, f"gbuffers_extractor.blks.{2 * i + 1}.1.0")
+        g = g + r  # Residual, model.py:17-19
+    fmap_buff = g
+    # main, model.py:82-95
+    x = ca(np.concatenate((up, fmap_buff), axis=1), "main.conv_in.0")
+    for i in range(6):
+        t = ca(x, f"main.conv_main.{i}.blks.0")
+        t = ca(t, f"main.conv_main.{i}.blks.2", act=0)
+        x = np.float32(0.2) * t + x  # model.py:33
+    x = ca(np.concatenate((up, x), axis=1), "after_main.0")
+    x = ca(x, "final_conv.0")
+    sr = ca(x, "final_conv.2", act=0)
+    if return_intermediates:
+        return sr, {"fmap_curr": fmap_curr, "up": up, "fmap_buff": fmap_buff}
+    return sr
+
+
+def reprfn_forward_deploy(sd, x):
+    """core/arch/RepRFN.py:327-339 in deploy form (state dict after switch_to_deploy())."""
+    def conv(x, key, stride=1, padding=1, act=0, slope=0.0):
+        return conv2d(x, sd[key + ".weight"], sd[key + ".bias"], stride, padding, act=act, slope=slope)
+
+    def esa(x, p):  # RepRFN.py:295-308
+        c1_ = conv(x, p + ".conv1", padding=0)
+        c1 = conv(c1_, p + ".conv2", stride=2, padding=0)
+        v_max = max_pool2d(c1, 7, 3)
+        c3 = conv(v_max, p + ".conv3", padding=1)
+        c3 = resize_bilinear(c3, x.shape[2], x.shape[3])
+        cf = conv(c1_, p + ".conv_f", padding=0)
+        c4 = conv(c3 + cf, p + ".conv4", padding=0)
+        m = np.float32(1.0) / (np.float32(1.0) + np.exp(-c4, dtype=np.float32))
+        return x * m
+
+    x = _c(x)
+    feat = conv(x, "fea_conv")
+    out = feat
+    for k in range(1, 5):
+        p = f"reprfb{k}"
+        inp = out
+        o = inp
+        for j in range(1, 4):
+            o = conv(o, f"{p}.repblock{j}.rbr_reparam", act=2, slope=0.05)
+        o = conv(o, f"{p}.conv3", act=2, slope=0.05)
+        o = inp + o
+        out = esa(o, f"{p}.esa")
+    out = conv(out, "lr_conv")
+    out = out + feat
+    out = conv(out, "upsampler.conv")
+    r = int(round((out.shape[1] // 3) ** 0.5))
+    return pixel_shuffle(out, r)

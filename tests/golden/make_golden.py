@@ -1,0 +1,289 @@
+"""Generate the golden fixtures in tests/golden/ by importing the reference on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference modules are imported unmodified; third-party modules that only do
+I/O (torchvision, cv2, omegaconf -- none on the arithmetic path) are replaced by
+empty stubs so the import succeeds.  Outputs are small .npz files of inputs and
+expected outputs; no reference source text is stored.
+
+Known reference defect handled here: core/tools/math.py:16-17 stacks the warp
+grid on dim=-1 and then permutes it again, which only runs when H == 2.  The
+warp goldens therefore call F.grid_sample with the grid the function evidently
+means to build (gx, gy exactly as math.py:12-15, stacked on the last dim).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = os.environ.get("SR_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_modules():
+    for name in ["torchvision", "torchvision.utils", "torchvision.models",
+                 "torchvision.models.feature_extraction", "cv2", "omegaconf"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.utils"].save_image = lambda *a, **k: None
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchvision.models"].feature_extraction = sys.modules["torchvision.models.feature_extraction"]
+    sys.modules["omegaconf"].OmegaConf = object
+    sys.path.insert(0, REF)
+
+
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def to_u16(t: torch.Tensor) -> np.ndarray:
+    """bf16-representable fp32 tensor -> uint16 bit pattern (halves fixture size)."""
+    return (t.contiguous().view(torch.int32) >> 16).to(torch.int16).numpy().view(np.uint16)
+
+
+def rnd(gen, *shape, lo=-1.0, hi=1.0):
+    return bf16_round(torch.rand(*shape, generator=gen) * (hi - lo) + lo)
+
+
+def gen_ops():
+    from core.tools.math import make_coord
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+
+    # ---- convolutions (nn.Conv2d call sites of model.py / RepRFN.py / model_final.py)
+    conv_cases = [
+        # name, N, Cin, Cout, H, W, kh, kw, stride, pad
+        ("c64_64", 1, 64, 64, 10, 37, 3, 3, 1, 1),
+        ("c10_64", 1, 10, 64, 9, 21, 3, 3, 1, 1),
+        ("c96_64", 1, 96, 64, 7, 19, 3, 3, 1, 1),
+        ("c64_3", 2, 64, 3, 8, 13, 3, 3, 1, 1),
+        ("c3_32", 1, 3, 32, 12, 20, 3, 3, 1, 1),
+        ("c32_32", 1, 32, 32, 12, 20, 3, 3, 1, 1),
+        ("c48_48", 1, 48, 48, 9, 14, 3, 3, 1, 1),
+        ("c48_16_1x1", 1, 48, 16, 9, 14, 1, 1, 1, 0),
+        ("c16_16_s2p0", 1, 16, 16, 15, 17, 3, 3, 2, 0),
+        ("c32_48_s2p1", 1, 32, 48, 12, 16, 3, 3, 2, 1),
+        ("c48_48_3x1", 1, 48, 48, 9, 14, 3, 1, 1, (1, 0)),
+        ("c48_48_1x3", 1, 48, 48, 9, 14, 1, 3, 1, (0, 1)),
+    ]
+    names = []
+    for (name, N, Cin, Cout, H, W, kh, kw, s, p) in conv_cases:
+        x = rnd(g, N, Cin, H, W)
+        w = bf16_round(torch.randn(Cout, Cin, kh, kw, generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5)
+        b = bf16_round(torch.randn(Cout, generator=g) * 0.1)
+        y = F.conv2d(x, w, b, stride=s, padding=p)
+        out[f"conv.{name}.x"] = x.numpy(); out[f"conv.{name}.w"] = w.numpy()
+        out[f"conv.{name}.b"] = b.numpy(); out[f"conv.{name}.y"] = y.numpy()
+        pp = p if isinstance(p, tuple) else (p, p)
+        out[f"conv.{name}.cfg"] = np.array([s, pp[0], pp[1]], np.int32)
+        names.append(name)
+    out["conv.names"] = np.array(names)
+
+    # ---- conv backward (autograd of nn.Conv2d): 64->64 and 10->64
+    for (name, Cin, Cout, H, W) in [("b64_64", 64, 64, 6, 9), ("b10_64", 10, 64, 5, 8), ("b64_3", 64, 3, 6, 7)]:
+        x = rnd(g, 2, Cin, H, W).requires_grad_(True)
+        w = bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5).requires_grad_(True)
+        b = torch.zeros(Cout, requires_grad=True)
+        dy = rnd(g, 2, Cout, H, W)
+        y = F.conv2d(x, w, b, padding=1)
+        y.backward(dy)
+        for k, v in (("x", x), ("w", w), ("dy", dy), ("dx", x.grad), ("dw", w.grad), ("db", b.grad)):
+            out[f"convbwd.{name}.{k}"] = v.detach().numpy()
+
+    # ---- make_coord (core/tools/math.py:107-130)
+    for (h, w) in [(3, 4), (12, 20), (48, 80), (7, 5), (270, 480), (1080, 1920), (2160, 3840)]:
+        c = make_coord((h, w))
+        # store only the two 1-D profiles: the field is separable
+        out[f"coord.{h}x{w}.x"] = c[0, 0, 0, :].numpy().copy()
+        out[f"coord.{h}x{w}.y"] = c[0, 1, :, 0].numpy().copy()
+
+    # ---- a-6: grid_sample(fmap, make_coord(th,tw)) bilinear zeros align_corners=False (model.py:153,162)
+    for (name, C, sh, sw, th, tw) in [("s4", 32, 5, 7, 20, 28), ("s2", 32, 6, 5, 12, 10), ("s3", 8, 4, 6, 12, 18)]:
+        x = rnd(g, 2, C, sh, sw)
+        coord = make_coord((th, tw)).expand(2, 2, th, tw)
+        y = F.grid_sample(x, coord.permute(0, 2, 3, 1), mode="bilinear", align_corners=False)
+        out[f"up.{name}.x"] = x.numpy(); out[f"up.{name}.y"] = y.numpy()
+    # backward of the same op
+    x = rnd(g, 1, 32, 5, 7).requires_grad_(True)
+    coord = make_coord((20, 28)).expand(1, 2, 20, 28)
+    y = F.grid_sample(x, coord.permute(0, 2, 3, 1), mode="bilinear", align_corners=False)
+    dy = rnd(g, 1, 32, 20, 28)
+    y.backward(dy)
+    out["upbwd.x"] = x.detach().numpy(); out["upbwd.dy"] = dy.numpy(); out["upbwd.dx"] = x.grad.numpy()
+
+    # ---- a-7: relative coordinates (code_test.py:193-202; lte.py:164-171)
+    for (sh, sw, s) in [(3, 4, 16), (6, 5, 2), (5, 7, 3), (5, 7, 4), (270, 480, 4)]:
+        th, tw = sh * s, sw * s
+        hr = make_coord((th, tw)).expand(1, 2, th, tw)
+        lr = make_coord((sh, sw)).expand(1, 2, sh, sw)
+        cs = F.grid_sample(lr, hr.permute(0, 2, 3, 1), mode="nearest", align_corners=False)
+        rel = hr - cs
+        rel[:, 0] *= sw
+        rel[:, 1] *= sh
+        if th * tw > 10000:  # separable: keep profiles only
+            out[f"rel.{sh}x{sw}x{s}.x"] = rel[0, 0, 0, :].numpy().copy()
+            out[f"rel.{sh}x{sw}x{s}.y"] = rel[0, 1, :, 0].numpy().copy()
+        else:
+            out[f"rel.{sh}x{sw}x{s}"] = rel.numpy()
+
+    # ---- a-9: backward_warping semantics (math.py:10-17 with the evident grid layout)
+    def warp(frame, motion, mode, align):
+        h, w = frame.shape[-2:]
+        gx = torch.arange(w).view(1, w).expand(h, -1).float()
+        gy = torch.arange(h).view(h, 1).expand(-1, w).float()
+        gx = ((gx[None, ...] + motion[:, 0]) / (w - 1)) * 2.0 - 1.0
+        gy = ((gy[None, ...] + motion[:, 1]) / (h - 1)) * 2.0 - 1.0
+        grid = torch.stack([gx, gy], dim=-1)
+        return F.grid_sample(frame, grid, mode, "zeros", align)
+
+    frame = rnd(g, 2, 13, 11, 17)
+    motion = torch.randn(2, 2, 11, 17, generator=g) * 2.5
+    motion[0, :, 0, :] = torch.tensor([-30.0, 40.0]).view(2, 1)  # out of frame
+    motion[1, :, 3, 4] = torch.tensor([0.5, -0.5])               # exact half-pixel
+    motion[1, :, 5, :] = 0.0                                     # identity row
+    motion = bf16_round(motion)
+    out["warp.frame"] = frame.numpy(); out["warp.motion"] = motion.numpy()
+    for mode in ("bilinear", "nearest"):
+        for align in (True, False):
+            out[f"warp.{mode}.{int(align)}"] = warp(frame, motion, mode, align).numpy()
+    # MV accumulation step (model_final.py:22-24): mv1 = warp(mv1, mv0, bilinear, True) + mv0
+    mv0, mv1 = motion[:1], motion[1:]
+    out["warp.accum"] = (warp(mv1, mv0, "bilinear", True) + mv0).numpy()
+    # backward (bilinear, align_corners=True) w.r.t. frame and motion
+    fr = frame.clone().requires_grad_(True); mo = motion.clone().requires_grad_(True)
+    yw = warp(fr, mo, "bilinear", True)
+    dyw = rnd(g, *yw.shape)
+    yw.backward(dyw)
+    out["warpbwd.dy"] = dyw.numpy(); out["warpbwd.dframe"] = fr.grad.numpy(); out["warpbwd.dmotion"] = mo.grad.numpy()
+
+    # ---- a-10: pixel shuffle / unshuffle (RepRFN.py:272; model_final.py:234,449)
+    for r in (2, 4):
+        x = torch.arange(2 * 3 * r * r * 5 * 7, dtype=torch.float32).view(2, 3 * r * r, 5, 7)
+        out[f"ps.{r}.x"] = x.numpy(); out[f"ps.{r}.y"] = F.pixel_shuffle(x, r).numpy()
+        z = torch.arange(2 * 10 * (3 * r) * (4 * r), dtype=torch.float32).view(2, 10, 3 * r, 4 * r)
+        out[f"pu.{r}.x"] = z.numpy(); out[f"pu.{r}.y"] = F.pixel_unshuffle(z, r).numpy()
+
+    # ---- a-11: nearest down-sampling (trainer.py:92-95)
+    for s in (2, 3, 4):
+        x = torch.arange(2 * 3 * 24 * 36, dtype=torch.float32).view(2, 3, 24, 36)
+        y = F.interpolate(x, scale_factor=1.0 / s, mode="nearest")
+        out[f"nd.{s}.x"] = x.numpy(); out[f"nd.{s}.y"] = y.numpy()
+
+    # ---- a-8: channels-first LayerNorm (CAMixerSR.py:32-37; formula evaluated with torch ops,
+    #      the class itself cannot be imported: its module needs basicsr)
+    x = rnd(g, 2, 60, 6, 9, lo=-2.0, hi=2.0)
+    wt = bf16_round(torch.rand(60, generator=g) + 0.5); bs = bf16_round(torch.randn(60, generator=g) * 0.1)
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    y = (x - u) / torch.sqrt(s + 1e-6)
+    y = wt[:, None, None] * y + bs[:, None, None]
+    out["ln.x"] = x.numpy(); out["ln.w"] = wt.numpy(); out["ln.b"] = bs.numpy(); out["ln.y"] = y.numpy()
+
+    # ---- ESA helpers (RepRFN.py:298,303)
+    x = rnd(g, 1, 16, 23, 29)
+    out["mp.x"] = x.numpy(); out["mp.y"] = F.max_pool2d(x, kernel_size=7, stride=3).numpy()
+    x = rnd(g, 1, 16, 5, 7)
+    out["rb.x"] = x.numpy(); out["rb.y"] = F.interpolate(x, (23, 31), mode="bilinear", align_corners=False).numpy()
+
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    print("ops.npz", len(out), "arrays")
+
+
+def gen_supersampler():
+    from core.models.model import SuperSampler, LossGroup
+    torch.manual_seed(42)
+    m = SuperSampler(3, 10, 1)
+    # bf16-representable weights and small random biases (the zero-bias init would hide bias bugs)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(bf16_round(torch.randn(p.shape, generator=g) * 0.05))
+            else:
+                p.copy_(bf16_round(p))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    B, L, sh, sw, s = 1, 2, 12, 20, 4
+    lr = rnd(g, B, L, 3, sh, sw, lo=0.0, hi=1.0)
+    hb = rnd(g, B, L, 10, sh * s, sw * s, lo=0.0, hi=1.0)
+    hr = rnd(g, B, 3, sh * s, sw * s, lo=0.0, hi=1.0)
+    batch = {"lr_frames": lr.clone(), "hr_buffers": hb.clone(), "hr_frames": hr, "scale": 4.0}
+    outb = m(batch)
+    sr = outb["sr_frames"]
+    loss_group = LossGroup(1.0, 0.5)
+    loss, loss_dict = loss_group({"hr_frames": hr, "sr_frames": torch.clip(sr, 0.0, 10.0)})
+    loss.backward()
+
+    out = {"lr_frames": lr.numpy(), "hr_buffers": hb.numpy(), "hr_frames": hr.numpy(),
+           "sr_frames": sr.detach().numpy(), "loss": np.float32(loss.item()),
+           "loss_l1": np.float32(loss_dict["l1"]), "loss_ssim": np.float32(loss_dict["ssim"])}
+    out["keys"] = np.array(list(sd.keys()))
+    for k, v in sd.items():
+        out["sd." + k] = to_u16(v)
+    for name, p in m.named_parameters():
+        gr = p.grad.detach()
+        out["grad." + name] = gr.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "supersampler.npz"), **out)
+    print("supersampler.npz: loss", loss.item(), loss_dict, "sr mean", sr.abs().mean().item())
+
+    # one AdamW step as core/trainer.py:158-161 with configs/trainer/4x_H2.yaml:12-17 hyper-parameters
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt.step()
+    step = {}
+    for name in ["frame_extractor.blks.0.0.weight", "main.conv_main.3.blks.2.weight", "final_conv.2.bias",
+                 "final_conv.2.weight"]:
+        step["after." + name] = dict(m.named_parameters())[name].detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "supersampler_step.npz"), **step)
+
+
+def gen_reprfn():
+    from core.arch.RepRFN import RepRFN, RepBlock
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(11)
+    # (1) re-parameterisation of one RepBlock (RepRFN.py:193-241, SeqConv3x3.rep_params :132-146)
+    blk = RepBlock(48, 48, "lrelu", deploy=False)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.requires_grad:
+                p.copy_(bf16_round(p))
+    x = rnd(g, 1, 48, 9, 14)
+    y_train = blk(x)
+    k, b = blk.get_equivalent_kernel_bias()
+    out = {"blk.x": x.numpy(), "blk.y": y_train.detach().numpy(), "blk.k": k.detach().numpy(), "blk.b": b.detach().numpy()}
+    out["blk.keys"] = np.array(list(blk.state_dict().keys()))
+    for kk, v in blk.state_dict().items():
+        out["blk.sd." + kk] = v.detach().numpy()
+
+    # (2) full network, deploy form, bf16-representable weights
+    m = RepRFN(3, 3, 48, 4, deploy=False)
+    for mod in m.modules():
+        if hasattr(mod, "switch_to_deploy"):
+            mod.switch_to_deploy()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(bf16_round(p))
+    m.eval()
+    xin = rnd(g, 1, 3, 16, 24, lo=0.0, hi=1.0)
+    with torch.no_grad():
+        y = m(xin)
+    out["net.x"] = xin.numpy(); out["net.y"] = y.numpy()
+    out["net.keys"] = np.array(list(m.state_dict().keys()))
+    for kk, v in m.state_dict().items():
+        out["net.sd." + kk] = to_u16(v)
+    np.savez_compressed(os.path.join(OUT, "reprfn.npz"), **out)
+    print("reprfn.npz: y mean", y.abs().mean().item(), "params", sum(p.numel() for p in m.parameters()))
+
+
+if __name__ == "__main__":
+    _stub_modules()
+    torch.set_num_threads(8)
+    gen_ops()
+    gen_supersampler()
+    gen_reprfn()
