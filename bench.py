@@ -1,0 +1,174 @@
+"""Benchmark of the super-resolution hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload infer4k|train]
+
+Default workload (BASELINE.json configs[1]): 4x SR inference 540p -> 2160p (4K), batch 1, bf16
+compute, default network (core/models/model.py SuperSampler), synthetic frames, seed-42 weights.
+A step = one forward pass over one frame whose inputs are already resident in HBM.  With N > 1
+ranks (one process per GPU, launched by torch.distributed.run) frames are sharded across ranks
+with no data-path collective (weak scaling); the value is whole-job frames/s.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the 64->64 3x3 MFMA
+convolution at 4K: 21 of the 25 HR layers), timed per launch with events on the launch stream;
+`cpu_baseline` times the CPU oracle on a bounded crop of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LR_H, LR_W, SCALE = 540, 960, 4
+HR_H, HR_W = LR_H * SCALE, LR_W * SCALE
+# algorithmic work of the default network per frame (conv FLOP = 2*MAC, bias/activation excluded)
+FLOP_PER_HR_PX = 2 * 892224
+FLOP_PER_LR_PX = 2 * 19296
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="infer4k", choices=["infer4k"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[96, 128], help="LR crop (h w) of the CPU-oracle sample")
+    return ap.parse_args()
+
+
+def make_model(dev):
+    from superresolution_amd import SuperSampler
+    torch.manual_seed(42)  # main.py:40 seeds with 42
+    return SuperSampler(3, 10, 1).to(dev).eval()
+
+
+def make_inputs(dev, rank):
+    g = torch.Generator().manual_seed(42 + rank)
+    lr = torch.rand(1, 2, 3, LR_H, LR_W, generator=g)
+    hb = torch.rand(1, 2, 10, HR_H, HR_W, generator=g)
+    hb[:, :, 9] *= 3.0  # depth channel range
+    return lr.to(dev), hb.to(dev)
+
+
+def dominant_kernel_time_ms(model, dev, iters):
+    """Average duration of one launch of the 64->64 3x3 convolution at 4K, measured with events
+    on the stream the kernel is launched on (torch's current stream)."""
+    from superresolution_amd import functional as F_
+    conv = model.main.conv_main[0].blks[0]
+    x = (torch.rand(1, HR_H, HR_W, 64, device=dev) - 0.5).to(torch.bfloat16)
+    wp = F_.conv3x3_pack_weights(conv.weight.detach(), 64, 64)
+    out = torch.empty_like(x)
+    for _ in range(3):
+        F_.conv3x3(x, wp, conv.bias.detach(), 64, act=F_.ACT_RELU, out=out)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        F_.conv3x3(x, wp, conv.bias.detach(), 64, act=F_.ACT_RELU, out=out)
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def cpu_baseline(crop):
+    """Oracle (CPU port of the reference path) on a bounded crop, scaled to 4K frames/s."""
+    import numpy as np
+    from oracle import oracle as orc
+    from superresolution_amd import SuperSampler
+    cores = min(16, os.cpu_count() or 1)
+    orc.set_threads(cores)
+    torch.manual_seed(42)
+    sd = {k: v.numpy() for k, v in SuperSampler(3, 10, 1).state_dict().items()}
+    ch, cw = crop
+    rng = np.random.default_rng(42)
+    lr = rng.random((1, 1, 3, ch, cw), dtype=np.float32)
+    hb = rng.random((1, 1, 10, ch * SCALE, cw * SCALE), dtype=np.float32)
+    orc.supersampler_forward(sd, lr[:, :, :, :8, :8], hb[:, :, :, :32, :32])  # page in
+    t0 = time.perf_counter()
+    orc.supersampler_forward(sd, lr, hb)
+    dt = time.perf_counter() - t0
+    frac = (ch * cw) / float(LR_H * LR_W)
+    return {"value": frac / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle forward on one LR {ch}x{cw} -> HR {ch * SCALE}x{cw * SCALE} crop ({dt:.2f} s), "
+                      f"scaled by pixel count to a 540x960 -> 2160x3840 frame"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    model = make_model(dev)
+    lr, hb = make_inputs(dev, rank)
+
+    def step():
+        return model.infer(lr[:, -1], hb[:, -1])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape == (1, 3, HR_H, HR_W) and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        fps = world * args.steps / dt
+        flop_frame = FLOP_PER_HR_PX * HR_H * HR_W + FLOP_PER_LR_PX * LR_H * LR_W
+        k_avg_ms, k_med_ms = dominant_kernel_time_ms(model, dev, 20)
+        k_flop = 2.0 * HR_H * HR_W * 64 * 64 * 9
+        achieved = k_flop / (k_avg_ms * 1e-3) / 1e12
+        res = {
+            "metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "4x SR inference 540x960 -> 2160x3840, default SuperSampler (4x_H2), batch 1 per GPU, "
+                                   "frames sharded by rank", "frames_per_step_per_gpu": 1,
+                       "tflop_per_frame": flop_frame / 1e12,
+                       "net_tflops": flop_frame / 1e12 / (ms_per_step * 1e-3),
+                       "net_frac_of_bf16_mfma_peak": flop_frame / 1e12 / (ms_per_step * 1e-3) / BF16_MFMA_PEAK_TFLOPS},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel<KC=4,CT=2> (64->64 3x3 @ 2160x3840)",
+                         "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": k_avg_ms, "median_launch_ms": k_med_ms,
+                         "algorithmic_flop_per_launch": k_flop,
+                         "algorithmic_bytes_per_launch": 2.0 * HR_H * HR_W * 64 * 2},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_crop)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,183 @@
+/*
+ * srhip.h -- C ABI of libsrhip.so, the MI355X (gfx950) implementation of the
+ * convolutional super-resolution hot path.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless a parameter is documented as host.
+ *   - The caller owns every buffer (inputs, outputs, packed weights); the library
+ *     never transfers ownership and never synchronises the device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Every function returns 0 on success and a negative srhip_status on error;
+ *     srhip_last_error() returns a thread-local, human-readable message.
+ *   - Activations travel between kernels as NHWC bf16 with a channel count that
+ *     is a multiple of 16 (zero padded); the reference's fp32 NCHW tensors enter
+ *     and leave through the layout kernels below.
+ *
+ * The reference has no native interface for this path (it calls torch.nn
+ * operators); each entry point cites the reference operator call it replaces.
+ */
+#ifndef SRHIP_H
+#define SRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRHIP_API __attribute__((visibility("default")))
+
+typedef enum {
+    SRHIP_OK = 0,
+    SRHIP_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    SRHIP_ERR_LAUNCH = -2,    /* HIP runtime error */
+    SRHIP_ERR_DEVICE = -3     /* not a gfx950 device / no device */
+} srhip_status;
+
+typedef enum { SRHIP_ACT_NONE = 0, SRHIP_ACT_RELU = 1, SRHIP_ACT_LRELU = 2 } srhip_act;
+typedef enum { SRHIP_BILINEAR = 0, SRHIP_NEAREST = 1 } srhip_interp;
+
+SRHIP_API int srhip_version(void);
+SRHIP_API const char* srhip_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Layout kernels (boundary between the reference's fp32 NCHW tensors and the
+ * internal NHWC bf16 activations).  HBM-bound.
+ * ------------------------------------------------------------------------- */
+/* src (N,C,H,W) fp32 -> dst (N,H,W,cpad) bf16, channels [C,cpad) zero filled.
+ * Replaces the implicit layout of the tensors handed to nn.Conv2d at
+ * core/models/model.py:161,167. */
+SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w,
+                                          int cpad, void* stream);
+/* src (N,H,W,cstride) bf16 -> dst (N,C,H,W) fp32 (first C channels). */
+SRHIP_API int srhip_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w,
+                                          int cstride, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution on CDNA4 MFMA (implicit GEMM, bf16 in,
+ * fp32 accumulate).  Replaces nn.Conv2d(+ReLU/LeakyReLU, + residual) at
+ * core/models/model.py:10-14 (ConvActivation), :17-19 (Residual), :22-33
+ * (SRResidualBlock: 0.2*f(x)+x), :111-115 (final_conv) and the 3x3 layers of
+ * core/arch/RepRFN.py:158-161,252,315,322 (deploy form).
+ *
+ *   dst = alpha * act(conv(concat(src_a, src_b)) + bias) + res
+ *
+ * The channel concat of core/models/model.py:169-170 is folded into the K loop:
+ * src_b may be NULL (cb = 0).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const void* src_a;   /* (N,H,W,ca) bf16, ca % 16 == 0 */
+    const void* src_b;   /* (N,H,W,cb) bf16 or NULL, cb % 16 == 0 */
+    const void* wpack;   /* packed weights, see srhip_conv3x3_pack_weights */
+    const float* bias;   /* fp32[cout] or NULL */
+    const void* res;     /* optional residual, (N,H,W,cout_stride) bf16 */
+    void* dst;           /* (N,H,W,cout_stride) bf16, or (N,cout,H,W) fp32 if dst_nchw_f32 */
+    int n, h, w;
+    int ca, cb;          /* padded channel counts of src_a / src_b */
+    int cout;            /* real output channels (<= 64) */
+    int cout_stride;     /* channels of dst/res in NHWC form (multiple of 8, >= cout) */
+    int act;             /* srhip_act */
+    float slope;         /* LeakyReLU negative slope */
+    float alpha;         /* scale applied after the activation (1.0 for none) */
+    int dst_nchw_f32;    /* 1: write fp32 NCHW (network output / fp32-accumulate checks); no residual */
+} srhip_conv3x3_args;
+
+/* Bytes of the packed-weight buffer for a (ca+cb) -> cout 3x3 layer. */
+SRHIP_API size_t srhip_conv3x3_packed_bytes(int cin_padded, int cout);
+
+/* Packs fp32 OIHW master weights (device) into MFMA fragment order (bf16).
+ *   w:        (w_o, w_i, 3, 3) fp32 -- nn.Conv2d.weight layout
+ *   cout, cout_off: this launch computes output channels [cout_off, cout_off+cout)
+ *   cin_*_real / c*_pad: real and padded channel counts of the two sources
+ *   transpose_flip = 0: forward.  Uses W[cout_off+co][ci][ky][kx]; needs
+ *                       w_i == cin_a_real + cin_b_real.
+ *   transpose_flip = 1: data-gradient form W'[co][ci][ky][kx] = W[ci][cout_off+co][2-ky][2-kx]
+ *                       (the "sources" carry dL/dy with w_o channels, the output is dL/dx for
+ *                       forward input channels [cout_off, cout_off+cout)).
+ */
+SRHIP_API int srhip_conv3x3_pack_weights(const float* w, void* wpack, int w_o, int w_i, int cout,
+                                         int cout_off, int cin_a_real, int ca_pad, int cin_b_real,
+                                         int cb_pad, int transpose_flip, void* stream);
+
+SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Generic direct convolution (any kernel size / stride / padding, NHWC bf16,
+ * fp32 accumulate on the vector ALU).  For the small memory-bound layers:
+ * ESA 1x1 / strided 3x3 (core/arch/RepRFN.py:285-291), 3x1 / 1x3 RepBlock
+ * branches (:165-168), stride-2 encoders (core/models/model_final.py:272-276).
+ * w is fp32 OIHW (device).  dst = alpha*act(conv+bias) + res.
+ * ------------------------------------------------------------------------- */
+SRHIP_API int srhip_conv2d_direct(const void* src, const float* w, const float* bias, const void* res,
+                                  void* dst, int n, int h, int wd, int cin, int cin_stride, int cout,
+                                  int cout_stride, int kh, int kw, int sh, int sw, int ph, int pw,
+                                  int act, float slope, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Memory-bound operators.
+ * ------------------------------------------------------------------------- */
+/* Fixed-ratio bilinear up-sampling with the reference's exact border rule:
+ * F.grid_sample(fmap, make_coord((th,tw)), "bilinear", zeros, align_corners=False)
+ * (core/models/model.py:153,162; make_coord core/tools/math.py:107-130).
+ * src (N,sh,sw,c) bf16 -> dst (N,th,tw,c) bf16, c % 8 == 0. */
+SRHIP_API int srhip_upsample_grid_bilinear_nhwc(const void* src, void* dst, int n, int c, int sh,
+                                                int sw, int th, int tw, void* stream);
+/* Same operator on the reference's fp32 NCHW tensors. */
+SRHIP_API int srhip_upsample_grid_bilinear_f32(const float* src, float* dst, int n, int c, int sh,
+                                               int sw, int th, int tw, void* stream);
+/* Its backward: dsrc (N,C,sh,sw) fp32 is ZEROED then accumulated (scatter-add). */
+SRHIP_API int srhip_upsample_grid_bilinear_bwd_f32(const float* ddst, float* dsrc, int n, int c,
+                                                   int sh, int sw, int th, int tw, void* stream);
+
+/* Motion-vector backward warp, core/tools/math.py:10-17 (grid (x,y)-last as the
+ * function evidently intends): frame (N,C,h,w), motion (N,2,h,w) in pixels,
+ * zero padding.  fp32 NCHW in/out. */
+SRHIP_API int srhip_backward_warp_f32(const float* frame, const float* motion, float* dst, int n,
+                                      int c, int h, int w, int mode, int align_corners, void* stream);
+/* bf16 NHWC frame, fp32 (N,2,h,w) motion. c % 8 == 0. */
+SRHIP_API int srhip_backward_warp_nhwc(const void* frame, const float* motion, void* dst, int n,
+                                       int c, int h, int w, int mode, int align_corners, void* stream);
+/* Backward of the bilinear warp: dframe (zeroed, then scatter-add) and dmotion. */
+SRHIP_API int srhip_backward_warp_bwd_f32(const float* frame, const float* motion, const float* ddst,
+                                          float* dframe, float* dmotion, int n, int c, int h, int w,
+                                          int align_corners, void* stream);
+
+/* nn.PixelShuffle / nn.PixelUnshuffle (core/arch/RepRFN.py:272,276;
+ * core/models/model_final.py:234,408,449).  Pure permutation on NCHW tensors of
+ * elem_size 2 or 4 bytes: bit-exact.
+ *   shuffle:   src (N,C*r*r,H,W) -> dst (N,C,H*r,W*r)
+ *   unshuffle: src (N,C,H*r,W*r) -> dst (N,C*r*r,H,W)          */
+SRHIP_API int srhip_pixel_shuffle(const void* src, void* dst, int n, int c, int h, int w, int r,
+                                  int elem_size, void* stream);
+SRHIP_API int srhip_pixel_unshuffle(const void* src, void* dst, int n, int c, int h, int w, int r,
+                                    int elem_size, void* stream);
+/* Fused network head: NHWC bf16 (N,H,W,cstride>=c*r*r) -> NCHW fp32 (N,c,H*r,W*r). */
+SRHIP_API int srhip_pixel_shuffle_nhwc_to_nchw_f32(const void* src, float* dst, int n, int c, int h,
+                                                   int w, int r, int cstride, void* stream);
+
+/* F.interpolate(x, scale_factor=1/s, mode="nearest") (core/trainer.py:92-95):
+ * src (NC,H,W) -> dst (NC,ho,wo), source index min(floor(dst*s'), size-1), s' = fp32(1/scale_factor). */
+SRHIP_API int srhip_nearest_down(const void* src, void* dst, int nc, int h, int w, int ho, int wo,
+                                 double scale_factor, int elem_size, void* stream);
+
+/* Relative-coordinate features (code_test.py:193-202, core/models/lte.py:164-171):
+ * dst (2,th,tw) fp32, bit-exact replay of the fp32 operator sequence. */
+SRHIP_API int srhip_rel_coord(float* dst, int th, int tw, int sh, int sw, void* stream);
+/* make_coord (core/tools/math.py:107-130): dst (2,h,w) fp32, ch0 = x, ch1 = y. */
+SRHIP_API int srhip_make_coord(float* dst, int h, int w, void* stream);
+
+/* torch.concat along channels (core/models/model.py:169-170) for NHWC bf16:
+ * dst (P, ca+cb) <- a (P,ca), b (P,cb); ca, cb % 8 == 0.  (The conv kernel
+ * folds the concat; this standalone form exists for callers that need the tensor.) */
+SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t pixels, int ca, int cb,
+                                void* stream);
+
+/* Channels-first LayerNorm (core/arch/CAMixerSR.py:32-37): x (N,C,HW) fp32. */
+SRHIP_API int srhip_layernorm_cf_f32(const float* x, const float* weight, const float* bias, float* y,
+                                     int n, int c, int hw, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRHIP_H */

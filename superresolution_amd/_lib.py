@@ -1,0 +1,73 @@
+"""ctypes binding of libsrhip.so (declared in include/srhip.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrhip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C superresolution_amd/csrc` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_int, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,
+                                                ctypes.c_void_p, ctypes.c_size_t)
+
+
+class Conv3x3Args(ctypes.Structure):
+    """srhip_conv3x3_args"""
+    _fields_ = [
+        ("src_a", c_void_p), ("src_b", c_void_p), ("wpack", c_void_p), ("bias", c_void_p),
+        ("res", c_void_p), ("dst", c_void_p),
+        ("n", c_int), ("h", c_int), ("w", c_int),
+        ("ca", c_int), ("cb", c_int),
+        ("cout", c_int), ("cout_stride", c_int),
+        ("act", c_int), ("slope", c_float), ("alpha", c_float),
+        ("dst_nchw_f32", c_int),
+    ]
+
+
+_SIGNATURES = {
+    "srhip_version": (c_int, []),
+    "srhip_last_error": (ctypes.c_char_p, []),
+    "srhip_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "srhip_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "srhip_conv3x3_packed_bytes": (c_size_t, [c_int, c_int]),
+    "srhip_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_int, c_void_p]),
+    "srhip_conv3x3_fwd": (c_int, [ctypes.POINTER(Conv3x3Args), c_void_p]),
+    "srhip_conv2d_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 +
+                            [c_int, c_float, c_float, c_void_p]),
+    "srhip_upsample_grid_bilinear_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_upsample_grid_bilinear_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_upsample_grid_bilinear_bwd_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_backward_warp_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_backward_warp_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_backward_warp_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "srhip_pixel_shuffle": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_pixel_unshuffle": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_pixel_shuffle_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_nearest_down": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_double, c_int, c_void_p]),
+    "srhip_rel_coord": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p]),
+    "srhip_make_coord": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "srhip_concat_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "srhip_layernorm_cf_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p]),
+}
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = tuple(_SIGNATURES)
+
+
+class SrhipError(RuntimeError):
+    pass
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise SrhipError(f"libsrhip status {status}: {lib.srhip_last_error().decode()}")

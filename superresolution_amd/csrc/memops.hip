@@ -1,0 +1,582 @@
+// HBM-bound operators of the super-resolution path: layout changes, grid-sample style
+// resampling (fixed-ratio up-sampling and motion-vector warp), pixel (un)shuffle, nearest
+// down-sampling, coordinate features, channel concat and channels-first LayerNorm.
+// One thread moves 16 bytes wherever the layout allows it; grids are capped and grid-strided.
+#include "srhip_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline int grid_for(long long work, int ncu) {
+    long long g = (work + kThreads - 1) / kThreads;
+    const long long cap = (long long)ncu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------
+// make_coord replay (fp32 operator sequence of the reference): coord(n, j) = base + step * j
+// with base = fp32(-1 + 1/n), step = fp32(2 * (1/n)) formed in double on the host.
+// ------------------------------------------------------------------------------------------
+struct CoordAxis { float base, step; };
+inline CoordAxis coord_axis(int n) {
+    const double r = 2.0 / (2.0 * (double)n);
+    CoordAxis a; a.step = (float)(2.0 * r); a.base = (float)(-1.0 + r); return a;
+}
+__device__ __forceinline__ float coord_val(CoordAxis a, int j) {
+    return __fadd_rn(a.base, __fmul_rn(a.step, (float)j));  // two separate fp32 roundings, no fma
+}
+// ATen grid_sampler unnormalize
+__device__ __forceinline__ float unnorm(float c, int size, bool align) {
+    return align ? __fmul_rn(__fdiv_rn(__fadd_rn(c, 1.0f), 2.0f), (float)(size - 1))
+                 : __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(c, 1.0f), (float)size), 1.0f), 2.0f);
+}
+
+struct Taps {  // bilinear footprint with zero padding
+    int x0, y0;
+    float wnw, wne, wsw, wse;
+    bool vx0, vx1, vy0, vy1;
+};
+__device__ __forceinline__ Taps make_taps(float ix, float iy, int W, int H) {
+    Taps t;
+    const float fx = floorf(ix), fy = floorf(iy);
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    const float x1f = fx + 1.0f, y1f = fy + 1.0f;
+    t.wnw = __fmul_rn(x1f - ix, y1f - iy);
+    t.wne = __fmul_rn(ix - fx, y1f - iy);
+    t.wsw = __fmul_rn(x1f - ix, iy - fy);
+    t.wse = __fmul_rn(ix - fx, iy - fy);
+    t.vx0 = t.x0 >= 0 && t.x0 < W; t.vx1 = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    t.vy0 = t.y0 >= 0 && t.y0 < H; t.vy1 = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout kernels
+// ------------------------------------------------------------------------------------------
+template <int CPAD>
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                             int n, int c, long long hw)
+{
+    const long long total = (long long)n * hw;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (long long)gridDim.x * blockDim.x) {
+        const long long img = p / hw, pix = p - img * hw;
+        const float* s = src + img * c * hw + pix;
+        unsigned out[CPAD / 2];
+#pragma unroll
+        for (int k = 0; k < CPAD / 2; ++k) {
+            const float a = (2 * k < c) ? s[(long long)(2 * k) * hw] : 0.0f;
+            const float b = (2 * k + 1 < c) ? s[(long long)(2 * k + 1) * hw] : 0.0f;
+            out[k] = pack_bf16x2(a, b);
+        }
+        uint4* d = (uint4*)(dst + p * CPAD);
+#pragma unroll
+        for (int k = 0; k < CPAD / 8; ++k) d[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    }
+}
+
+__global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst,
+                                             int n, int c, long long hw, int cstride)
+{
+    const long long total = (long long)n * hw;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (long long)gridDim.x * blockDim.x) {
+        const long long img = p / hw, pix = p - img * hw;
+        const unsigned short* s = src + p * cstride;
+        float* d = dst + img * c * hw + pix;
+        for (int k = 0; k < c; ++k) d[(long long)k * hw] = bf16_bits_to_f32(s[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grid-sample family.  NHWC bf16: one thread = one output pixel x 8 channels (16 B).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void blend8(const unsigned short* __restrict__ src, long long img_base, int W, int C,
+                                       int c0, const Taps& t, unsigned short* __restrict__ out)
+{
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tap = [&](int y, int x, float wgt) {
+        const uint4 v = *(const uint4*)(src + (img_base + (long long)y * W + x) * C + c0);
+        acc[0] += bf16_lo(v.x) * wgt; acc[1] += bf16_hi(v.x) * wgt;
+        acc[2] += bf16_lo(v.y) * wgt; acc[3] += bf16_hi(v.y) * wgt;
+        acc[4] += bf16_lo(v.z) * wgt; acc[5] += bf16_hi(v.z) * wgt;
+        acc[6] += bf16_lo(v.w) * wgt; acc[7] += bf16_hi(v.w) * wgt;
+    };
+    if (t.vy0 && t.vx0) tap(t.y0, t.x0, t.wnw);
+    if (t.vy0 && t.vx1) tap(t.y0, t.x0 + 1, t.wne);
+    if (t.vy1 && t.vx0) tap(t.y0 + 1, t.x0, t.wsw);
+    if (t.vy1 && t.vx1) tap(t.y0 + 1, t.x0 + 1, t.wse);
+    *(uint4*)out = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                              pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+}
+
+__global__ void upsample_nhwc_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                     int n, int c, int sh, int sw, int th, int tw, CoordAxis ax, CoordAxis ay)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * th * tw * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int x = (int)(p % tw); p /= tw;
+        const int y = (int)(p % th);
+        const int img = (int)(p / th);
+        const float ix = unnorm(coord_val(ax, x), sw, false);
+        const float iy = unnorm(coord_val(ay, y), sh, false);
+        const Taps t = make_taps(ix, iy, sw, sh);
+        blend8(src, (long long)img * sh * sw, sw, c, g * 8, t, dst + (((long long)img * th + y) * tw + x) * c + g * 8);
+    }
+}
+
+__global__ void warp_nhwc_kernel(const unsigned short* __restrict__ frame, const float* __restrict__ motion,
+                                 unsigned short* __restrict__ dst, int n, int c, int h, int w, int mode, int align)
+{
+    const int cg = c / 8;
+    const long long hw = (long long)h * w;
+    const long long total = (long long)n * hw * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int x = (int)(p % w); p /= w;
+        const int y = (int)(p % h);
+        const int img = (int)(p / h);
+        const float mx = motion[((long long)img * 2 + 0) * hw + (long long)y * w + x];
+        const float my = motion[((long long)img * 2 + 1) * hw + (long long)y * w + x];
+        const float gx = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)x, mx), (float)(w - 1)), 2.0f), 1.0f);
+        const float gy = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)y, my), (float)(h - 1)), 2.0f), 1.0f);
+        const float ix = unnorm(gx, w, align), iy = unnorm(gy, h, align);
+        unsigned short* o = dst + (((long long)img * h + y) * w + x) * c + g * 8;
+        if (mode == SRHIP_BILINEAR) {
+            const Taps t = make_taps(ix, iy, w, h);
+            blend8(frame, (long long)img * hw, w, c, g * 8, t, o);
+        } else {
+            const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (xn >= 0 && xn < w && yn >= 0 && yn < h)
+                v = *(const uint4*)(frame + ((long long)img * hw + (long long)yn * w + xn) * c + g * 8);
+            *(uint4*)o = v;
+        }
+    }
+}
+
+// fp32 NCHW grid-sample: one thread = one output pixel, loops over channels (coalesced along x).
+// GRID_FROM: 0 = make_coord grid (fixed-ratio up-sampling), 1 = motion vectors.
+template <int GRID_FROM>
+__global__ void sample_f32_kernel(const float* __restrict__ src, const float* __restrict__ motion,
+                                  float* __restrict__ dst, int n, int c, int sh, int sw, int th, int tw, int mode,
+                                  int align, CoordAxis ax, CoordAxis ay)
+{
+    const long long thw = (long long)th * tw, shw = (long long)sh * sw;
+    const long long total = (long long)n * thw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(i / thw);
+        const long long pix = i - (long long)img * thw;
+        const int y = (int)(pix / tw), x = (int)(pix - (long long)y * tw);
+        float gx, gy;
+        if (GRID_FROM == 0) {
+            gx = coord_val(ax, x); gy = coord_val(ay, y);
+        } else {
+            const float mx = motion[((long long)img * 2 + 0) * thw + pix];
+            const float my = motion[((long long)img * 2 + 1) * thw + pix];
+            gx = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)x, mx), (float)(tw - 1)), 2.0f), 1.0f);
+            gy = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)y, my), (float)(th - 1)), 2.0f), 1.0f);
+        }
+        const float ix = unnorm(gx, sw, align), iy = unnorm(gy, sh, align);
+        const float* s = src + (long long)img * c * shw;
+        float* d = dst + (long long)img * c * thw + pix;
+        if (mode == SRHIP_BILINEAR) {
+            const Taps t = make_taps(ix, iy, sw, sh);
+            const long long o00 = (long long)t.y0 * sw + t.x0;
+            for (int k = 0; k < c; ++k) {
+                const float* sp = s + (long long)k * shw;
+                float v = 0.0f;
+                if (t.vy0 && t.vx0) v = __fadd_rn(v, __fmul_rn(sp[o00], t.wnw));
+                if (t.vy0 && t.vx1) v = __fadd_rn(v, __fmul_rn(sp[o00 + 1], t.wne));
+                if (t.vy1 && t.vx0) v = __fadd_rn(v, __fmul_rn(sp[o00 + sw], t.wsw));
+                if (t.vy1 && t.vx1) v = __fadd_rn(v, __fmul_rn(sp[o00 + sw + 1], t.wse));
+                d[(long long)k * thw] = v;
+            }
+        } else {
+            const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+            const bool ok = xn >= 0 && xn < sw && yn >= 0 && yn < sh;
+            for (int k = 0; k < c; ++k)
+                d[(long long)k * thw] = ok ? s[(long long)k * shw + (long long)yn * sw + xn] : 0.0f;
+        }
+    }
+}
+
+// backward of the bilinear sampler: scatter-add into dsrc (fp32 atomics), optional dmotion.
+template <int GRID_FROM>
+__global__ void sample_bwd_f32_kernel(const float* __restrict__ src, const float* __restrict__ motion,
+                                      const float* __restrict__ ddst, float* __restrict__ dsrc,
+                                      float* __restrict__ dmotion, int n, int c, int sh, int sw, int th, int tw,
+                                      int align, CoordAxis ax, CoordAxis ay)
+{
+    const long long thw = (long long)th * tw, shw = (long long)sh * sw;
+    const long long total = (long long)n * thw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int img = (int)(i / thw);
+        const long long pix = i - (long long)img * thw;
+        const int y = (int)(pix / tw), x = (int)(pix - (long long)y * tw);
+        float gx, gy;
+        if (GRID_FROM == 0) {
+            gx = coord_val(ax, x); gy = coord_val(ay, y);
+        } else {
+            const float mx = motion[((long long)img * 2 + 0) * thw + pix];
+            const float my = motion[((long long)img * 2 + 1) * thw + pix];
+            gx = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)x, mx), (float)(tw - 1)), 2.0f), 1.0f);
+            gy = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)y, my), (float)(th - 1)), 2.0f), 1.0f);
+        }
+        const float ix = unnorm(gx, sw, align), iy = unnorm(gy, sh, align);
+        const Taps t = make_taps(ix, iy, sw, sh);
+        const float wx1 = ix - floorf(ix), wx0 = 1.0f - wx1;
+        const float wy1 = iy - floorf(iy), wy0 = 1.0f - wy1;
+        const long long o00 = (long long)t.y0 * sw + t.x0;
+        float gix = 0.0f, giy = 0.0f;
+        for (int k = 0; k < c; ++k) {
+            const float g = ddst[((long long)img * c + k) * thw + pix];
+            float* dp = dsrc + ((long long)img * c + k) * shw;
+            const float* sp = (GRID_FROM == 1) ? src + ((long long)img * c + k) * shw : nullptr;
+            if (t.vy0 && t.vx0) { atomicAdd(dp + o00, g * t.wnw); if (GRID_FROM == 1) { const float v = sp[o00]; gix -= v * wy0 * g; giy -= v * wx0 * g; } }
+            if (t.vy0 && t.vx1) { atomicAdd(dp + o00 + 1, g * t.wne); if (GRID_FROM == 1) { const float v = sp[o00 + 1]; gix += v * wy0 * g; giy -= v * wx1 * g; } }
+            if (t.vy1 && t.vx0) { atomicAdd(dp + o00 + sw, g * t.wsw); if (GRID_FROM == 1) { const float v = sp[o00 + sw]; gix -= v * wy1 * g; giy += v * wx0 * g; } }
+            if (t.vy1 && t.vx1) { atomicAdd(dp + o00 + sw + 1, g * t.wse); if (GRID_FROM == 1) { const float v = sp[o00 + sw + 1]; gix += v * wy1 * g; giy += v * wx1 * g; } }
+        }
+        if (GRID_FROM == 1 && dmotion) {
+            // d ix / d gx = (W-1)/2 (align) or W/2; d gx / d mx = 2/(W-1)
+            const float sx = (align ? (float)(sw - 1) * 0.5f : (float)sw * 0.5f) * (2.0f / (float)(tw - 1));
+            const float sy = (align ? (float)(sh - 1) * 0.5f : (float)sh * 0.5f) * (2.0f / (float)(th - 1));
+            dmotion[((long long)img * 2 + 0) * thw + pix] = gix * sx;
+            dmotion[((long long)img * 2 + 1) * thw + pix] = giy * sy;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pixel shuffle / unshuffle (pure permutations), nearest down-sampling
+// ------------------------------------------------------------------------------------------
+template <typename T, bool UNSHUFFLE>
+__global__ void pixel_shuffle_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int c, int h, int w, int r)
+{
+    // "big" tensor (N,C,H*r,W*r), "deep" tensor (N,C*r*r,H,W); thread index runs over the big one.
+    const long long total = (long long)n * c * h * r * w * r;
+    const int wr = w * r, hr = h * r;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % wr);
+        long long t = i / wr;
+        const int Y = (int)(t % hr); t /= hr;
+        const int ch = (int)(t % c);
+        const int img = (int)(t / c);
+        const int yy = Y / r, ii = Y - yy * r, xx = X / r, jj = X - xx * r;
+        const long long deep = (((long long)img * c * r * r + (long long)ch * r * r + ii * r + jj) * h + yy) * w + xx;
+        if (UNSHUFFLE) dst[deep] = src[i];
+        else dst[i] = src[deep];
+    }
+}
+
+__global__ void pixel_shuffle_nhwc_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst,
+                                                      int n, int c, int h, int w, int r, int cstride)
+{
+    const long long total = (long long)n * c * h * r * w * r;
+    const int wr = w * r, hr = h * r;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % wr);
+        long long t = i / wr;
+        const int Y = (int)(t % hr); t /= hr;
+        const int ch = (int)(t % c);
+        const int img = (int)(t / c);
+        const int yy = Y / r, ii = Y - yy * r, xx = X / r, jj = X - xx * r;
+        dst[i] = bf16_bits_to_f32(src[(((long long)img * h + yy) * w + xx) * cstride + ch * r * r + ii * r + jj]);
+    }
+}
+
+template <typename T>
+__global__ void nearest_down_kernel(const T* __restrict__ src, T* __restrict__ dst, int nc, int h, int w, int ho,
+                                    int wo, float inv)
+{
+    const long long total = (long long)nc * ho * wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo);
+        long long t = i / wo;
+        const int oy = (int)(t % ho);
+        const long long pl = t / ho;
+        int iy = (int)floorf(__fmul_rn((float)oy, inv)); if (iy > h - 1) iy = h - 1;
+        int ix = (int)floorf(__fmul_rn((float)ox, inv)); if (ix > w - 1) ix = w - 1;
+        dst[i] = src[(pl * h + iy) * w + ix];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// coordinate features
+// ------------------------------------------------------------------------------------------
+__global__ void make_coord_kernel(float* __restrict__ dst, int h, int w, CoordAxis ax, CoordAxis ay)
+{
+    const long long hw = (long long)h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+        dst[i] = coord_val(ax, x);
+        dst[hw + i] = coord_val(ay, y);
+    }
+}
+
+__global__ void rel_coord_kernel(float* __restrict__ dst, int th, int tw, int sh, int sw, CoordAxis hx, CoordAxis hy,
+                                 CoordAxis lx, CoordAxis ly)
+{
+    const long long hw = (long long)th * tw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / tw), x = (int)(i - (long long)y * tw);
+        const float cx = coord_val(hx, x), cy = coord_val(hy, y);
+        const int xn = (int)nearbyintf(unnorm(cx, sw, false)), yn = (int)nearbyintf(unnorm(cy, sh, false));
+        float qx = 0.0f, qy = 0.0f;
+        if (xn >= 0 && xn < sw && yn >= 0 && yn < sh) { qx = coord_val(lx, xn); qy = coord_val(ly, yn); }
+        dst[i] = __fmul_rn(__fsub_rn(cx, qx), (float)sw);
+        dst[hw + i] = __fmul_rn(__fsub_rn(cy, qy), (float)sh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// concat (NHWC bf16, 16-B chunks) and channels-first LayerNorm (fp32 NCHW)
+// ------------------------------------------------------------------------------------------
+__global__ void concat_nhwc_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ dst,
+                                   long long pixels, int qa, int qb)
+{
+    const int q = qa + qb;
+    const long long total = pixels * q;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / q;
+        const int k = (int)(i - p * q);
+        dst[i] = k < qa ? a[p * qa + k] : b[p * qb + (k - qa)];
+    }
+}
+
+__global__ void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                    const float* __restrict__ bias, float* __restrict__ y, int n, int c, long long hw,
+                                    float eps)
+{
+    const long long total = (long long)n * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / hw, pix = i - img * hw;
+        const float* xp = x + img * c * hw + pix;
+        float* yp = y + img * c * hw + pix;
+        float u = 0.0f;
+        for (int k = 0; k < c; ++k) u += xp[(long long)k * hw];
+        u = u / (float)c;
+        float s = 0.0f;
+        for (int k = 0; k < c; ++k) { const float d = xp[(long long)k * hw] - u; s += d * d; }
+        s = s / (float)c;
+        const float den = sqrtf(s + eps);
+        for (int k = 0; k < c; ++k) yp[(long long)k * hw] = weight[k] * ((xp[(long long)k * hw] - u) / den) + bias[k];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, int cpad,
+                                          void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "nchw_f32_to_nhwc_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && c <= cpad, "nchw_f32_to_nhwc_bf16: bad shape");
+    const long long hw = (long long)h * w;
+    const int g = grid_for((long long)n * hw, srhip_num_cus());
+    hipStream_t s = (hipStream_t)stream;
+    switch (cpad) {
+        case 16: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<16>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
+        case 32: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<32>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
+        case 48: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<48>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
+        case 64: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<64>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
+        default: srhip_set_error("nchw_f32_to_nhwc_bf16: cpad must be 16, 32, 48 or 64 (got %d)", cpad); return SRHIP_ERR_INVALID;
+    }
+    return srhip_check_launch("nchw_f32_to_nhwc_bf16");
+}
+
+SRHIP_API int srhip_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, int cstride,
+                                          void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "nhwc_bf16_to_nchw_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && c <= cstride, "nhwc_bf16_to_nchw_f32: bad shape");
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)src, dst, n, c, hw, cstride);
+    return srhip_check_launch("nhwc_bf16_to_nchw_f32");
+}
+
+SRHIP_API int srhip_upsample_grid_bilinear_nhwc(const void* src, void* dst, int n, int c, int sh, int sw, int th,
+                                                int tw, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "upsample_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && sh >= 1 && sw >= 1 && th >= 1 && tw >= 1, "upsample_nhwc: bad shape");
+    const long long work = (long long)n * th * tw * (c / 8);
+    hipLaunchKernelGGL(upsample_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, (unsigned short*)dst, n, c, sh, sw, th, tw, coord_axis(tw), coord_axis(th));
+    return srhip_check_launch("upsample_nhwc");
+}
+
+SRHIP_API int srhip_upsample_grid_bilinear_f32(const float* src, float* dst, int n, int c, int sh, int sw, int th,
+                                               int tw, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "upsample_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && sh >= 1 && sw >= 1 && th >= 1 && tw >= 1, "upsample_f32: bad shape");
+    hipLaunchKernelGGL(sample_f32_kernel<0>, dim3(grid_for((long long)n * th * tw, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, src, (const float*)nullptr, dst, n, c, sh, sw, th, tw, (int)SRHIP_BILINEAR, 0,
+                       coord_axis(tw), coord_axis(th));
+    return srhip_check_launch("upsample_f32");
+}
+
+SRHIP_API int srhip_upsample_grid_bilinear_bwd_f32(const float* ddst, float* dsrc, int n, int c, int sh, int sw, int th,
+                                                   int tw, void* stream)
+{
+    SRHIP_REQUIRE(ddst && dsrc, "upsample_bwd_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && sh >= 1 && sw >= 1 && th >= 1 && tw >= 1, "upsample_bwd_f32: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dsrc, 0, (size_t)n * c * sh * sw * sizeof(float), s) != hipSuccess) {
+        srhip_set_error("upsample_bwd_f32: memset failed");
+        return SRHIP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(sample_bwd_f32_kernel<0>, dim3(grid_for((long long)n * th * tw, srhip_num_cus())), dim3(kThreads), 0, s,
+                       (const float*)nullptr, (const float*)nullptr, ddst, dsrc, (float*)nullptr, n, c, sh, sw, th, tw, 0,
+                       coord_axis(tw), coord_axis(th));
+    return srhip_check_launch("upsample_bwd_f32");
+}
+
+SRHIP_API int srhip_backward_warp_f32(const float* frame, const float* motion, float* dst, int n, int c, int h, int w,
+                                      int mode, int align_corners, void* stream)
+{
+    SRHIP_REQUIRE(frame && motion && dst, "backward_warp_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 2 && w >= 2, "backward_warp_f32: bad shape (h, w must be >= 2)");
+    SRHIP_REQUIRE(mode == SRHIP_BILINEAR || mode == SRHIP_NEAREST, "backward_warp_f32: bad mode %d", mode);
+    hipLaunchKernelGGL(sample_f32_kernel<1>, dim3(grid_for((long long)n * h * w, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, frame, motion, dst, n, c, h, w, h, w, mode, align_corners ? 1 : 0, CoordAxis{0, 0},
+                       CoordAxis{0, 0});
+    return srhip_check_launch("backward_warp_f32");
+}
+
+SRHIP_API int srhip_backward_warp_nhwc(const void* frame, const float* motion, void* dst, int n, int c, int h, int w,
+                                       int mode, int align_corners, void* stream)
+{
+    SRHIP_REQUIRE(frame && motion && dst, "backward_warp_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && h >= 2 && w >= 2, "backward_warp_nhwc: bad shape");
+    SRHIP_REQUIRE(mode == SRHIP_BILINEAR || mode == SRHIP_NEAREST, "backward_warp_nhwc: bad mode %d", mode);
+    hipLaunchKernelGGL(warp_nhwc_kernel, dim3(grid_for((long long)n * h * w * (c / 8), srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)frame, motion, (unsigned short*)dst, n, c, h, w, mode,
+                       align_corners ? 1 : 0);
+    return srhip_check_launch("backward_warp_nhwc");
+}
+
+SRHIP_API int srhip_backward_warp_bwd_f32(const float* frame, const float* motion, const float* ddst, float* dframe,
+                                          float* dmotion, int n, int c, int h, int w, int align_corners, void* stream)
+{
+    SRHIP_REQUIRE(frame && motion && ddst && dframe, "backward_warp_bwd_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 2 && w >= 2, "backward_warp_bwd_f32: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dframe, 0, (size_t)n * c * h * w * sizeof(float), s) != hipSuccess) {
+        srhip_set_error("backward_warp_bwd_f32: memset failed");
+        return SRHIP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(sample_bwd_f32_kernel<1>, dim3(grid_for((long long)n * h * w, srhip_num_cus())), dim3(kThreads), 0, s,
+                       frame, motion, ddst, dframe, dmotion, n, c, h, w, h, w, align_corners ? 1 : 0, CoordAxis{0, 0},
+                       CoordAxis{0, 0});
+    return srhip_check_launch("backward_warp_bwd_f32");
+}
+
+SRHIP_API int srhip_pixel_shuffle(const void* src, void* dst, int n, int c, int h, int w, int r, int elem_size,
+                                  void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "pixel_shuffle: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && r >= 1, "pixel_shuffle: bad shape");
+    const int g = grid_for((long long)n * c * h * r * w * r, srhip_num_cus());
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_size == 4) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned, false>), dim3(g), dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, n, c, h, w, r);
+    else if (elem_size == 2) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned short, false>), dim3(g), dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, n, c, h, w, r);
+    else { srhip_set_error("pixel_shuffle: elem_size must be 2 or 4"); return SRHIP_ERR_INVALID; }
+    return srhip_check_launch("pixel_shuffle");
+}
+
+SRHIP_API int srhip_pixel_unshuffle(const void* src, void* dst, int n, int c, int h, int w, int r, int elem_size,
+                                    void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "pixel_unshuffle: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && r >= 1, "pixel_unshuffle: bad shape");
+    const int g = grid_for((long long)n * c * h * r * w * r, srhip_num_cus());
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_size == 4) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned, true>), dim3(g), dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, n, c, h, w, r);
+    else if (elem_size == 2) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned short, true>), dim3(g), dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, n, c, h, w, r);
+    else { srhip_set_error("pixel_unshuffle: elem_size must be 2 or 4"); return SRHIP_ERR_INVALID; }
+    return srhip_check_launch("pixel_unshuffle");
+}
+
+SRHIP_API int srhip_pixel_shuffle_nhwc_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, int r,
+                                                   int cstride, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "pixel_shuffle_nhwc_to_nchw_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && r >= 1 && cstride >= c * r * r, "pixel_shuffle_nhwc_to_nchw_f32: bad shape");
+    hipLaunchKernelGGL(pixel_shuffle_nhwc_to_nchw_f32_kernel, dim3(grid_for((long long)n * c * h * r * w * r, srhip_num_cus())),
+                       dim3(kThreads), 0, (hipStream_t)stream, (const unsigned short*)src, dst, n, c, h, w, r, cstride);
+    return srhip_check_launch("pixel_shuffle_nhwc_to_nchw_f32");
+}
+
+SRHIP_API int srhip_nearest_down(const void* src, void* dst, int nc, int h, int w, int ho, int wo, double scale_factor,
+                                 int elem_size, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "nearest_down: null pointer");
+    SRHIP_REQUIRE(nc >= 1 && h >= 1 && w >= 1 && ho >= 1 && wo >= 1 && scale_factor > 0.0, "nearest_down: bad shape");
+    const float inv = (float)(1.0 / scale_factor);
+    const int g = grid_for((long long)nc * ho * wo, srhip_num_cus());
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_size == 4) hipLaunchKernelGGL(nearest_down_kernel<unsigned>, dim3(g), dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, nc, h, w, ho, wo, inv);
+    else if (elem_size == 2) hipLaunchKernelGGL(nearest_down_kernel<unsigned short>, dim3(g), dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, nc, h, w, ho, wo, inv);
+    else { srhip_set_error("nearest_down: elem_size must be 2 or 4"); return SRHIP_ERR_INVALID; }
+    return srhip_check_launch("nearest_down");
+}
+
+SRHIP_API int srhip_rel_coord(float* dst, int th, int tw, int sh, int sw, void* stream)
+{
+    SRHIP_REQUIRE(dst, "rel_coord: null pointer");
+    SRHIP_REQUIRE(th >= 1 && tw >= 1 && sh >= 1 && sw >= 1, "rel_coord: bad shape");
+    hipLaunchKernelGGL(rel_coord_kernel, dim3(grid_for((long long)th * tw, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, dst, th, tw, sh, sw, coord_axis(tw), coord_axis(th), coord_axis(sw), coord_axis(sh));
+    return srhip_check_launch("rel_coord");
+}
+
+SRHIP_API int srhip_make_coord(float* dst, int h, int w, void* stream)
+{
+    SRHIP_REQUIRE(dst, "make_coord: null pointer");
+    SRHIP_REQUIRE(h >= 1 && w >= 1, "make_coord: bad shape");
+    hipLaunchKernelGGL(make_coord_kernel, dim3(grid_for((long long)h * w, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, dst, h, w, coord_axis(w), coord_axis(h));
+    return srhip_check_launch("make_coord");
+}
+
+SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t pixels, int ca, int cb, void* stream)
+{
+    SRHIP_REQUIRE(a && b && dst, "concat_nhwc: null pointer");
+    SRHIP_REQUIRE(ca >= 8 && cb >= 8 && ca % 8 == 0 && cb % 8 == 0, "concat_nhwc: channels must be multiples of 8");
+    const long long work = (long long)pixels * ((ca + cb) / 8);
+    hipLaunchKernelGGL(concat_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)a, (const uint4*)b, (uint4*)dst, (long long)pixels, ca / 8, cb / 8);
+    return srhip_check_launch("concat_nhwc");
+}
+
+SRHIP_API int srhip_layernorm_cf_f32(const float* x, const float* weight, const float* bias, float* y, int n, int c, int hw,
+                                     float eps, void* stream)
+{
+    SRHIP_REQUIRE(x && weight && bias && y, "layernorm_cf_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && hw >= 1, "layernorm_cf_f32: bad shape");
+    hipLaunchKernelGGL(layernorm_cf_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, x, weight, bias, y, n, c, (long long)hw, eps);
+    return srhip_check_launch("layernorm_cf_f32");
+}
+
+}  // extern "C"

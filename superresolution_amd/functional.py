@@ -1,0 +1,282 @@
+"""Tensor-level wrappers over the C ABI of libsrhip.so.
+
+Every function takes/returns torch tensors that live on a ROCm device; torch is used only to
+own device memory and to name the current HIP stream.  NHWC tensors are plain contiguous
+``(N, H, W, C)`` bf16 tensors (not torch "channels_last" views).
+"""
+from typing import Optional
+
+import torch
+
+from ._lib import Conv3x3Args, check, lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+_MODES = {"bilinear": 0, "nearest": 1}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a tensor on the GPU (libsrhip has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def pad16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+# ------------------------------------------------------------------------------------------------
+# layout
+# ------------------------------------------------------------------------------------------------
+def nchw_f32_to_nhwc_bf16(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    x = _req(x, torch.float32, "x")
+    n, c, h, w = x.shape
+    cpad = pad16(c) if cpad is None else cpad
+    out = torch.empty((n, h, w, cpad), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_nchw_f32_to_nhwc_bf16(x.data_ptr(), out.data_ptr(), n, c, h, w, cpad, _stream()))
+    return out
+
+
+def nhwc_bf16_to_nchw_f32(x: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
+    x = _req(x, torch.bfloat16, "x")
+    n, h, w, cs = x.shape
+    c = cs if c is None else c
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(lib.srhip_nhwc_bf16_to_nchw_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, cs, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# 3x3 MFMA convolution
+# ------------------------------------------------------------------------------------------------
+def conv3x3_pack_weights(weight: torch.Tensor, cin_a_real: int, ca_pad: int, cin_b_real: int = 0, cb_pad: int = 0,
+                         cout: Optional[int] = None, cout_off: int = 0, transpose_flip: bool = False) -> torch.Tensor:
+    """fp32 (O,I,3,3) master weights -> packed bf16 fragments (opaque uint8 tensor)."""
+    weight = _req(weight, torch.float32, "weight")
+    w_o, w_i, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("conv3x3_pack_weights: kernel must be 3x3")
+    if cout is None:
+        cout = w_i if transpose_flip else w_o
+    nbytes = lib.srhip_conv3x3_packed_bytes(ca_pad + cb_pad, cout)
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+    check(lib.srhip_conv3x3_pack_weights(weight.data_ptr(), packed.data_ptr(), w_o, w_i, cout, cout_off, cin_a_real,
+                                         ca_pad, cin_b_real, cb_pad, int(transpose_flip), _stream()))
+    return packed
+
+
+def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+            src_b: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+            slope: float = 0.0, alpha: float = 1.0, out_nchw_f32: bool = False,
+            cout_stride: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dst = alpha * act(conv3x3(concat(src_a, src_b)) + bias) + res   (NHWC bf16 activations)."""
+    src_a = _req(src_a, torch.bfloat16, "src_a")
+    n, h, w, ca = src_a.shape
+    cb = 0
+    if src_b is not None:
+        src_b = _req(src_b, torch.bfloat16, "src_b")
+        if src_b.shape[:3] != src_a.shape[:3]:
+            raise ValueError("conv3x3: src_a and src_b disagree on (N,H,W)")
+        cb = src_b.shape[3]
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias")
+    if cout_stride is None:
+        cout_stride = pad16(cout)
+    if out_nchw_f32:
+        if out is None:
+            out = torch.empty((n, cout, h, w), dtype=torch.float32, device=src_a.device)
+    else:
+        if out is None:
+            out = torch.empty((n, h, w, cout_stride), dtype=torch.bfloat16, device=src_a.device)
+        if res is not None:
+            res = _req(res, torch.bfloat16, "res")
+            if tuple(res.shape) != (n, h, w, cout_stride):
+                raise ValueError("conv3x3: residual shape must equal the output shape")
+    a = Conv3x3Args(src_a=src_a.data_ptr(), src_b=_ptr(src_b), wpack=wpack.data_ptr(), bias=_ptr(bias),
+                    res=_ptr(res), dst=out.data_ptr(), n=n, h=h, w=w, ca=ca, cb=cb, cout=cout,
+                    cout_stride=cout_stride, act=act, slope=slope, alpha=alpha, dst_nchw_f32=int(out_nchw_f32))
+    check(lib.srhip_conv3x3_fwd(a, _stream()))
+    return out
+
+
+def conv2d_direct(src: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], cin: int, stride=1, padding=0,
+                  res: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0, alpha: float = 1.0,
+                  cout_stride: Optional[int] = None) -> torch.Tensor:
+    """Generic NHWC bf16 convolution (fp32 OIHW weights) for small / odd-shaped layers."""
+    src = _req(src, torch.bfloat16, "src")
+    weight = _req(weight, torch.float32, "weight")
+    n, h, w, cs = src.shape
+    cout, wcin, kh, kw = weight.shape
+    if wcin != cin:
+        raise ValueError("conv2d_direct: weight C_in does not match cin")
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    cout_stride = pad16(cout) if cout_stride is None else cout_stride
+    out = torch.empty((n, ho, wo, cout_stride), dtype=torch.bfloat16, device=src.device)
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias")
+    if res is not None:
+        res = _req(res, torch.bfloat16, "res")
+    check(lib.srhip_conv2d_direct(src.data_ptr(), weight.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), n, h, w, cin,
+                                  cs, cout, cout_stride, kh, kw, sh, sw, ph, pw, act, slope, alpha, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# memory-bound operators
+# ------------------------------------------------------------------------------------------------
+def upsample_grid_bilinear_nhwc(x: torch.Tensor, th: int, tw: int) -> torch.Tensor:
+    x = _req(x, torch.bfloat16, "x")
+    n, sh, sw, c = x.shape
+    out = torch.empty((n, th, tw, c), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_upsample_grid_bilinear_nhwc(x.data_ptr(), out.data_ptr(), n, c, sh, sw, th, tw, _stream()))
+    return out
+
+
+def upsample_grid_bilinear(x: torch.Tensor, th: int, tw: int) -> torch.Tensor:
+    """F.grid_sample(x, make_coord((th, tw)), bilinear, zeros, align_corners=False) on fp32 NCHW."""
+    x = _req(x, torch.float32, "x")
+    n, c, sh, sw = x.shape
+    out = torch.empty((n, c, th, tw), dtype=torch.float32, device=x.device)
+    check(lib.srhip_upsample_grid_bilinear_f32(x.data_ptr(), out.data_ptr(), n, c, sh, sw, th, tw, _stream()))
+    return out
+
+
+def upsample_grid_bilinear_bwd(dy: torch.Tensor, sh: int, sw: int) -> torch.Tensor:
+    dy = _req(dy, torch.float32, "dy")
+    n, c, th, tw = dy.shape
+    dx = torch.empty((n, c, sh, sw), dtype=torch.float32, device=dy.device)
+    check(lib.srhip_upsample_grid_bilinear_bwd_f32(dy.data_ptr(), dx.data_ptr(), n, c, sh, sw, th, tw, _stream()))
+    return dx
+
+
+def backward_warp(frame: torch.Tensor, motion: torch.Tensor, mode: str = "nearest", align_corners: bool = True) -> torch.Tensor:
+    """fp32 NCHW motion-vector warp (semantics of the reference's backward_warping)."""
+    frame = _req(frame, torch.float32, "frame")
+    motion = _req(motion, torch.float32, "motion")
+    n, c, h, w = frame.shape
+    if tuple(motion.shape) != (n, 2, h, w):
+        raise ValueError("backward_warp: motion must be (N,2,H,W)")
+    out = torch.empty_like(frame)
+    check(lib.srhip_backward_warp_f32(frame.data_ptr(), motion.data_ptr(), out.data_ptr(), n, c, h, w, _MODES[mode],
+                                      int(align_corners), _stream()))
+    return out
+
+
+def backward_warp_nhwc(frame: torch.Tensor, motion: torch.Tensor, mode: str = "bilinear", align_corners: bool = True) -> torch.Tensor:
+    frame = _req(frame, torch.bfloat16, "frame")
+    motion = _req(motion, torch.float32, "motion")
+    n, h, w, c = frame.shape
+    if tuple(motion.shape) != (n, 2, h, w):
+        raise ValueError("backward_warp_nhwc: motion must be (N,2,H,W)")
+    out = torch.empty_like(frame)
+    check(lib.srhip_backward_warp_nhwc(frame.data_ptr(), motion.data_ptr(), out.data_ptr(), n, c, h, w, _MODES[mode],
+                                       int(align_corners), _stream()))
+    return out
+
+
+def backward_warp_bwd(frame: torch.Tensor, motion: torch.Tensor, dy: torch.Tensor, align_corners: bool = True):
+    frame = _req(frame, torch.float32, "frame")
+    motion = _req(motion, torch.float32, "motion")
+    dy = _req(dy, torch.float32, "dy")
+    n, c, h, w = frame.shape
+    dframe = torch.empty_like(frame)
+    dmotion = torch.empty_like(motion)
+    check(lib.srhip_backward_warp_bwd_f32(frame.data_ptr(), motion.data_ptr(), dy.data_ptr(), dframe.data_ptr(),
+                                          dmotion.data_ptr(), n, c, h, w, int(align_corners), _stream()))
+    return dframe, dmotion
+
+
+def _elem(t: torch.Tensor) -> int:
+    if t.element_size() not in (2, 4):
+        raise TypeError("expected a 2- or 4-byte element type")
+    return t.element_size()
+
+
+def pixel_shuffle(x: torch.Tensor, r: int) -> torch.Tensor:
+    if not x.is_cuda:
+        raise ValueError("pixel_shuffle: expected a GPU tensor")
+    x = x.contiguous()
+    n, crr, h, w = x.shape
+    if crr % (r * r):
+        raise ValueError("pixel_shuffle: channels not divisible by r*r")
+    c = crr // (r * r)
+    out = torch.empty((n, c, h * r, w * r), dtype=x.dtype, device=x.device)
+    check(lib.srhip_pixel_shuffle(x.data_ptr(), out.data_ptr(), n, c, h, w, r, _elem(x), _stream()))
+    return out
+
+
+def pixel_unshuffle(x: torch.Tensor, r: int) -> torch.Tensor:
+    if not x.is_cuda:
+        raise ValueError("pixel_unshuffle: expected a GPU tensor")
+    x = x.contiguous()
+    n, c, hr, wr = x.shape
+    if hr % r or wr % r:
+        raise ValueError("pixel_unshuffle: spatial size not divisible by r")
+    h, w = hr // r, wr // r
+    out = torch.empty((n, c * r * r, h, w), dtype=x.dtype, device=x.device)
+    check(lib.srhip_pixel_unshuffle(x.data_ptr(), out.data_ptr(), n, c, h, w, r, _elem(x), _stream()))
+    return out
+
+
+def pixel_shuffle_nhwc_to_nchw_f32(x: torch.Tensor, c: int, r: int) -> torch.Tensor:
+    x = _req(x, torch.bfloat16, "x")
+    n, h, w, cs = x.shape
+    out = torch.empty((n, c, h * r, w * r), dtype=torch.float32, device=x.device)
+    check(lib.srhip_pixel_shuffle_nhwc_to_nchw_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, r, cs, _stream()))
+    return out
+
+
+def nearest_down(x: torch.Tensor, scale_factor: float) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=scale_factor, mode="nearest") for scale_factor <= 1 (NCHW)."""
+    if not x.is_cuda:
+        raise ValueError("nearest_down: expected a GPU tensor")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    ho, wo = int(h * scale_factor), int(w * scale_factor)
+    out = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device)
+    check(lib.srhip_nearest_down(x.data_ptr(), out.data_ptr(), n * c, h, w, ho, wo, float(scale_factor), _elem(x), _stream()))
+    return out
+
+
+def rel_coord(th: int, tw: int, sh: int, sw: int, device) -> torch.Tensor:
+    out = torch.empty((1, 2, th, tw), dtype=torch.float32, device=device)
+    check(lib.srhip_rel_coord(out.data_ptr(), th, tw, sh, sw, _stream()))
+    return out
+
+
+def make_coord(h: int, w: int, device) -> torch.Tensor:
+    out = torch.empty((1, 2, h, w), dtype=torch.float32, device=device)
+    check(lib.srhip_make_coord(out.data_ptr(), h, w, _stream()))
+    return out
+
+
+def concat_nhwc(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a = _req(a, torch.bfloat16, "a")
+    b = _req(b, torch.bfloat16, "b")
+    if a.shape[:-1] != b.shape[:-1]:
+        raise ValueError("concat_nhwc: leading dimensions differ")
+    out = torch.empty(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), dtype=torch.bfloat16, device=a.device)
+    pixels = a.numel() // a.shape[-1]
+    check(lib.srhip_concat_nhwc(a.data_ptr(), b.data_ptr(), out.data_ptr(), pixels, a.shape[-1], b.shape[-1], _stream()))
+    return out
+
+
+def layernorm_cf(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    x = _req(x, torch.float32, "x")
+    weight = _req(weight, torch.float32, "weight")
+    bias = _req(bias, torch.float32, "bias")
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    check(lib.srhip_layernorm_cf_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), n, c, h * w, eps, _stream()))
+    return y

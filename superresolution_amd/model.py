@@ -1,0 +1,152 @@
+"""Drop-in for the reference's default network, ``core.models.model.SuperSampler``
+(core/models/model.py:98-175), running on libsrhip.so.
+
+Contract kept (core/models/model.py:99,147-175; core/trainer.py:32-35,232,254):
+  * ctor ``SuperSampler(frame_channels=3, buffer_channels=10, n_history=1)``;
+  * ``forward(batch)`` pops ``lr_frames`` (B,L,3,sh,sw) / ``hr_buffers`` (B,L,10,th,tw), uses the
+    last frame of each, sets ``batch["sr_frames"]`` (B,3,th,tw) fp32 and returns the dict;
+  * identical ``state_dict`` keys / OIHW fp32 shapes and the same seed-for-seed initialisation
+    (xavier_normal_ weights, zero biases, modules built in the same order).
+
+Inside, activations are NHWC bf16, every convolution is one launch of the MFMA kernel with its
+bias / ReLU / residual / 0.2-scale fused, and both channel concats are folded into the consumer
+convolution (no concat tensor is materialised).
+"""
+from typing import Dict, List, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import functional as F_
+
+
+def _conv_act(cin: int, cout: int) -> nn.Sequential:
+    # parameter container with the reference's key layout "<name>.0.{weight,bias}"
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.ReLU(inplace=True))
+
+
+class _Residual(nn.Sequential):
+    """x + seq(x) in the reference (model.py:17-19); here only a parameter container."""
+
+
+class _SRResidualBlock(nn.Module):
+    def __init__(self, channels: int) -> None:
+        super().__init__()
+        self.blks = nn.Sequential(nn.Conv2d(channels, channels, 3, 1, 1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(channels, channels, 3, 1, 1))
+
+
+class _FrameExtractor(nn.Module):
+    def __init__(self, cin: int, widths: List[int]) -> None:
+        super().__init__()
+        blks, cur = [], cin
+        for wd in widths:
+            blks.append(_conv_act(cur, wd))
+            cur = wd
+        self.blks = nn.ModuleList(blks)
+
+
+class _GBuffersExtractor(nn.Module):
+    def __init__(self, cin: int, widths: List[int]) -> None:
+        super().__init__()
+        blks, cur = [], cin
+        for wd in widths:
+            blks += [_conv_act(cur, wd), _Residual(_conv_act(wd, wd), _conv_act(wd, wd))]
+            cur = wd
+        self.blks = nn.Sequential(*blks)
+
+
+class _MainNetwork(nn.Module):
+    def __init__(self, cin: int, ch: int, n_layers: int) -> None:
+        super().__init__()
+        self.conv_in = _conv_act(cin, ch)
+        self.conv_main = nn.ModuleList([_SRResidualBlock(ch) for _ in range(n_layers)])
+
+
+class SuperSampler(nn.Module):
+    FR_CH, BF_CH, SR_CH = 32, 64, 64
+
+    def __init__(self, frame_channels: int = 3, buffer_channels: int = 10, n_history: int = 1) -> None:
+        super().__init__()
+        fr, bf, sr = self.FR_CH, self.BF_CH, self.SR_CH
+        self.frame_extractor = _FrameExtractor(frame_channels, [fr, fr, fr])
+        self.gbuffers_extractor = _GBuffersExtractor(buffer_channels, [bf, bf, bf])
+        self.main = _MainNetwork(fr + bf, sr, 6)
+        self.after_main = _conv_act(sr + fr, sr)
+        self.final_conv = nn.Sequential(nn.Conv2d(sr, sr, 3, 1, 1), nn.ReLU(inplace=True),
+                                        nn.Conv2d(sr, frame_channels, 3, 1, 1))
+        self.n_history = n_history
+        self.frame_channels = frame_channels
+        self.buffer_channels = buffer_channels
+        self._init_parameters()
+        self._packs: Dict[str, tuple] = {}
+
+    def _init_parameters(self) -> None:
+        # same rule and same visiting order as core/models/model.py:120-132
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------ packed-weight cache
+    def _pack(self, name: str, conv: nn.Conv2d, cin_a: int, ca_pad: int, cin_b: int = 0, cb_pad: int = 0) -> Tensor:
+        w = conv.weight
+        tag = (w._version, w.data_ptr(), w.device)
+        hit = self._packs.get(name)
+        if hit is None or hit[0] != tag:
+            hit = (tag, F_.conv3x3_pack_weights(w.detach(), cin_a, ca_pad, cin_b, cb_pad))
+            self._packs[name] = hit
+        return hit[1]
+
+    def _conv(self, name: str, conv: nn.Conv2d, x: Tensor, cin_a: int, xb: Tensor = None, cin_b: int = 0,
+              res: Tensor = None, act: int = F_.ACT_RELU, alpha: float = 1.0, out_nchw_f32: bool = False) -> Tensor:
+        wp = self._pack(name, conv, cin_a, x.shape[-1], cin_b, 0 if xb is None else xb.shape[-1])
+        return F_.conv3x3(x, wp, conv.bias.detach(), conv.out_channels, src_b=xb, res=res, act=act, alpha=alpha,
+                          out_nchw_f32=out_nchw_f32)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch: Dict[str, Union[Tensor, int]]):
+        lr_frames = batch.pop("lr_frames")
+        hr_buffers = batch.pop("hr_buffers")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .training import supersampler_forward_train  # autograd path (fp32 master weights, bf16 compute)
+            batch["sr_frames"] = supersampler_forward_train(self, lr_frames[:, -1], hr_buffers[:, -1])
+            return batch
+        batch["sr_frames"] = self.infer(lr_frames[:, -1], hr_buffers[:, -1])
+        return batch
+
+    @torch.no_grad()
+    def infer(self, lr: Tensor, hb: Tensor) -> Tensor:
+        """lr (B,3,sh,sw) fp32, hb (B,10,th,tw) fp32 -> (B,3,th,tw) fp32."""
+        th, tw = hb.shape[-2:]
+        fc, bc, fr, bf = self.frame_channels, self.buffer_channels, self.FR_CH, self.BF_CH
+
+        # frame_extractor @ LR (model.py:50-58,161)
+        f = F_.nchw_f32_to_nhwc_bf16(lr.float())
+        cin = fc
+        for i, blk in enumerate(self.frame_extractor.blks):
+            f = self._conv(f"fe{i}", blk[0], f, cin)
+            cin = fr
+        # fixed-ratio bilinear up-sampling with the reference's zero-padded border (model.py:153,162)
+        up = F_.upsample_grid_bilinear_nhwc(f, th, tw)
+
+        # gbuffers_extractor @ HR (model.py:61-79,167)
+        g = F_.nchw_f32_to_nhwc_bf16(hb.float())
+        cin = bc
+        blks = self.gbuffers_extractor.blks
+        for i in range(0, len(blks), 2):
+            g = self._conv(f"ge{i}", blks[i][0], g, cin)
+            t = self._conv(f"ge{i + 1}a", blks[i + 1][0][0], g, bf)
+            g = self._conv(f"ge{i + 1}b", blks[i + 1][1][0], t, bf, res=g)  # x + relu(conv(.))
+            cin = bf
+
+        # main: concat(up, g) -> conv_in -> 6 x {x + 0.2 * conv(relu(conv(x)))}  (model.py:82-95,169)
+        x = self._conv("main_in", self.main.conv_in[0], up, fr, xb=g, cin_b=bf)
+        for i, blk in enumerate(self.main.conv_main):
+            t = self._conv(f"m{i}a", blk.blks[0], x, self.SR_CH)
+            x = self._conv(f"m{i}b", blk.blks[2], t, self.SR_CH, res=x, act=F_.ACT_NONE, alpha=0.2)
+        # after_main on concat(up, x) (model.py:170), final_conv (model.py:111-115,172)
+        x = self._conv("after", self.after_main[0], up, fr, xb=x, cin_b=self.SR_CH)
+        x = self._conv("fin0", self.final_conv[0], x, self.SR_CH)
+        return self._conv("fin2", self.final_conv[2], x, self.SR_CH, act=F_.ACT_NONE, out_nchw_f32=True)

@@ -200,6 +200,10 @@ def gen_supersampler():
     from core.models.model import SuperSampler, LossGroup
     torch.manual_seed(42)
     m = SuperSampler(3, 10, 1)
+    # digest of the seed-42 initialisation (first 8 values + fp64 sum of every parameter)
+    init = {name: np.concatenate([p.detach().numpy().ravel()[:8],
+                                  np.array([p.detach().double().sum().item()], np.float32)]).astype(np.float32)
+            for name, p in m.named_parameters()}
     # bf16-representable weights and small random biases (the zero-bias init would hide bias bugs)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
@@ -224,6 +228,8 @@ def gen_supersampler():
     out = {"lr_frames": lr.numpy(), "hr_buffers": hb.numpy(), "hr_frames": hr.numpy(),
            "sr_frames": sr.detach().numpy(), "loss": np.float32(loss.item()),
            "loss_l1": np.float32(loss_dict["l1"]), "loss_ssim": np.float32(loss_dict["ssim"])}
+    for k, v in init.items():
+        out["init." + k] = v
     out["keys"] = np.array(list(sd.keys()))
     for k, v in sd.items():
         out["sd." + k] = to_u16(v)

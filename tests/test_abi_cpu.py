@@ -1,0 +1,74 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol the header
+declares, and the Python mirror keeps the reference's state-dict contract."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "srhip.h")).read()
+    return sorted(set(re.findall(r"SRHIP_API\s+[\w\s\*]+?\b(srhip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from superresolution_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(_lib.lib, n), f"libsrhip.so does not export {n}"
+    # and the ctypes table covers exactly the header
+    assert sorted(_lib.EXPORTED) == names
+    assert _lib.lib.srhip_version() >= 1
+
+
+def test_conv_args_struct_layout():
+    from superresolution_amd._lib import Conv3x3Args
+    # 6 pointers + 11 4-byte scalars, padded to pointer alignment
+    assert ctypes.sizeof(Conv3x3Args) == 6 * 8 + 12 * 4
+    assert Conv3x3Args.n.offset == 48 and Conv3x3Args.dst_nchw_f32.offset == 48 + 10 * 4
+
+
+def test_packed_bytes():
+    from superresolution_amd._lib import lib
+    assert lib.srhip_conv3x3_packed_bytes(64, 64) == 9 * 4 * 2 * 64 * 16
+    assert lib.srhip_conv3x3_packed_bytes(96, 64) == 9 * 6 * 2 * 64 * 16
+    assert lib.srhip_conv3x3_packed_bytes(16, 3) == 9 * 1 * 1 * 64 * 16
+
+
+def test_supersampler_state_dict_contract(ss_golden):
+    from superresolution_amd import SuperSampler
+    z, sd = ss_golden
+    m = SuperSampler(3, 10, 1)
+    own = m.state_dict()
+    assert list(own.keys()) == [str(k) for k in z["keys"]]
+    for k, v in own.items():
+        assert tuple(v.shape) == sd[k].shape, k
+        assert v.dtype == torch.float32
+    assert sum(p.numel() for p in m.parameters()) == 913155
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+
+
+def test_supersampler_init_matches_reference_seed_for_seed(ss_golden):
+    from superresolution_amd import SuperSampler
+    z, _ = ss_golden
+    torch.manual_seed(42)
+    m = SuperSampler(3, 10, 1)
+    for name, p in m.named_parameters():
+        ref = z["init." + name]
+        got = p.detach().numpy().ravel()
+        assert np.array_equal(got[:8], ref[:-1]), name
+        assert np.float32(p.detach().double().sum().item()) == ref[-1], name
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    from superresolution_amd import functional as F_
+    with pytest.raises(ValueError):
+        F_.nchw_f32_to_nhwc_bf16(torch.zeros(1, 3, 4, 4))
+    with pytest.raises(ValueError):
+        F_.pixel_shuffle(torch.zeros(1, 4, 2, 2), 2)
