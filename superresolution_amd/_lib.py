@@ -10,6 +10,22 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C superresolution_amd/csrc` "
         "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
 
+
+def _load_hip_runtime() -> None:
+    """libsrhip.so carries no DT_NEEDED for the HIP runtime: it must bind to the ONE runtime this
+    process uses for device memory and streams, which is the copy PyTorch-ROCm loaded.  Promote
+    that copy to the global symbol scope before loading the kernels."""
+    import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+    cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"),
+            "/opt/rocm/lib/libamdhip64.so"]
+    for path in cand:
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            return
+    raise ImportError("no libamdhip64.so found (looked in torch/lib and /opt/rocm/lib)")
+
+
+_load_hip_runtime()
 lib = ctypes.CDLL(LIB_PATH)
 
 c_int, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,

@@ -4,6 +4,12 @@
 // One thread moves 16 bytes wherever the layout allows it; grids are capped and grid-strided.
 #include "srhip_common.h"
 
+// The coordinate / index arithmetic below replays the reference's fp32 operator sequence one
+// rounding at a time.  HIP's __fmul_rn / __fadd_rn are plain operators that the default
+// -ffp-contract=fast fuses into FMAs, so this file is compiled with -ffp-contract=off (Makefile)
+// and the pragma below covers the code written here.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int kThreads = 256;
