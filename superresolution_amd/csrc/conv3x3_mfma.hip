@@ -2,18 +2,26 @@
 //
 // Mapping (M = output channels, N = pixels, K = 9 taps x input channels):
 //   * v_mfma_f32_32x32x16_bf16 with A = weights (row = cout), B = pixels (col = pixel), so every
-//     lane ends up holding, for ONE pixel, runs of 4 consecutive output channels (NHWC friendly).
+//     lane ends up holding, for ONE pixel, runs of 4 consecutive output channels.
 //   * The whole weight tensor of the layer lives in REGISTERS for the life of the workgroup
-//     (9 * KC * NCT fragments of 4 VGPRs; the unified 512-entry VGPR/AGPR file at one wave per
-//     SIMD holds the 288 registers of a 64->64 layer), so LDS carries only activations.
+//     (9 * KC * NCT fragments of 4 registers, pinned to AGPRs / VGPRs through asm operands; the
+//     unified 512-entry file at one wave per SIMD holds the 288 registers of a 64->64 layer), so
+//     LDS carries only activations.
 //   * A workgroup walks a vertical strip of TW output columns top to bottom.  Input rows stream
-//     HBM -> LDS through a ring of rows filled by global_load_lds (LDS-DMA, 16 B per lane); every
-//     input row is fetched once per strip.  One wave = 32 consecutive pixels of the current row.
+//     HBM -> LDS through a ring of RING rows filled by global_load_lds (LDS-DMA, 16 B per lane),
+//     LA rows ahead of the row being computed; every input row is fetched once per strip.  One
+//     wave = 32 consecutive pixels of the current row.
 //   * LDS row image: [16-channel plane][pixel][32 B]; the two 16-B halves of a pixel are swapped
 //     when (pixel >> 3) & 1, which makes the ds_read_b128 of 32 consecutive pixels conflict free.
 //     LDS-DMA writes linearly, so the swap is applied to the per-lane SOURCE address.
 //   * Channel concat of two source tensors is folded into the K loop (planes of A then planes of B).
-//   * Epilogue: bias (as initial accumulator), activation, alpha, residual add, bf16 pack, store.
+//   * All waits are COUNTED (s_waitcnt vmcnt(N) / lgkmcnt(N) written by hand): every vector-memory
+//     operation is issued unconditionally (out-of-range lanes are dropped by buffer bounds checks),
+//     so the number of younger operations at each wait is a compile-time constant.
+//   * The epilogue of row i-1 (accumulators -> LDS -> pixel-major: bias, activation, scale,
+//     residual, bf16 pack, 16-byte whole-pixel stores) is sliced into micro-steps that are
+//     interleaved with the MFMAs of row i (two accumulator sets), so vector ALU work hides in the
+//     matrix pipe's shadow.
 #include "srhip_common.h"
 
 namespace {
@@ -30,14 +38,15 @@ struct ConvParams {
     int ca, cb;  // padded channels of the two sources
     int kc_a;    // 16-channel planes that come from src_a
     int cout, cout_stride;
-    int act;
-    float slope, alpha;
+    float slope, alpha;  // slope: 1 (no activation), 0 (ReLU) or the LeakyReLU slope
     int dst_nchw_f32;
     int nstrips, nsegs, seg_h, total_items;
 };
 
-template <int KC_, int CT_TOTAL_, int CSPLIT_>
+template <int KC_, int CT_TOTAL_, int CSPLIT_, bool OUT_F32_, bool HAS_RES_>
 struct Cfg {
+    static constexpr bool OUT_F32 = OUT_F32_;   // epilogue writes fp32 NCHW instead of bf16 NHWC
+    static constexpr bool HAS_RES = HAS_RES_;   // a residual tensor is added in the epilogue (bf16 NHWC only)
     static constexpr int KC = KC_;              // 16-channel K planes
     static constexpr int CT_TOTAL = CT_TOTAL_;  // 32-wide output-channel tiles of the layer
     static constexpr int CSPLIT = CSPLIT_;      // waves that share a pixel group (split over cout tiles)
@@ -51,10 +60,128 @@ struct Cfg {
     static constexpr int SLOT_CHUNKS = SLOT_BYTES / 16;
     static constexpr int NPIECE = (SLOT_CHUNKS + 63) / 64;          // 1 KiB LDS-DMA pieces per row
     static constexpr int MAXP = (NPIECE + NWAVES - 1) / NWAVES;     // pieces per wave per row
-    static constexpr int LA = 3;                                    // rows issued ahead
-    static constexpr int RING = 4;                                  // LDS row slots (power of two)
-    static constexpr int LDS_BYTES = RING * SLOT_BYTES;
+    static constexpr int LA = 5;                                    // rows issued ahead of the row being computed
+    static constexpr int RING = LA + 1;                             // LDS row slots
+    static constexpr int RING_BYTES = RING * SLOT_BYTES;
+    // Epilogue staging (bf16 NHWC output): the wave's 32 px x (32*NCT) fp32 results cross LDS once so
+    // that every store instruction writes whole pixels (16 B per lane, 1 KiB contiguous per wave).
+    static constexpr int NSLOT = 8 * NCT;                           // 16-B fp32 slots per staged pixel
+    static constexpr int PXS = NSLOT * 16;                          // staged bytes per pixel
+    static constexpr int LPP = NSLOT / 2;                           // lanes per pixel at store time (8 ch each)
+    static constexpr int PPI = 64 / LPP;                            // pixels per store instruction
+    static constexpr int NST = 2 * NCT;                             // 16-B stores per lane per row
+    static constexpr int STAGE_BYTES = OUT_F32 ? 0 : 32 * PXS;      // per wave
+    static constexpr int NSTORE = OUT_F32 ? 16 * NCT : NST;         // store instructions per wave per row
+    static constexpr int NRES = HAS_RES ? NST : 0;                  // residual load instructions per wave per row
+    // Vector-memory operations one wave issues per iteration i, in order:
+    //   [residual loads of row i] [LDS-DMA pieces of row i+LA] [output stores of row i-1]
+    // (fp32 NCHW output: stores of row i).  P = pieces of this wave (MAXP or MAXP-1).
+    // Top of iteration i waits for input row i+2, issued at iteration i+2-LA: younger operations are
+    // that iteration's stores and LA-3 whole iterations.
+    static constexpr int clamp63(int v) { return v > 63 ? 63 : v; }  // vmcnt is a 6-bit field; smaller = safe
+    static constexpr int top_wait_steady(int P) { return clamp63(NSTORE + (LA - 3) * (NRES + P + NSTORE)); }
+    // iterations 1 .. LA-3 of an item: the row was issued by the prologue; row 3's younger operations
+    // at iteration 1 are the fewest and bound all of them.
+    static constexpr int top_wait_early(int P) { return clamp63((LA - 4) * P + NRES + P + NSTORE); }
+    // Residual of row i-1 (loaded at the top of iteration i-1) is consumed in iteration i after the
+    // pieces of iteration i were issued: younger are pieces(i-1), stores(i-2), residual(i), pieces(i).
+    static constexpr int res_wait(int P) { return clamp63(2 * P + NSTORE + NRES); }
+    // ... and after the row loop (last row): younger are that iteration's pieces and stores.
+    static constexpr int res_wait_tail(int P) { return clamp63(P + NSTORE); }
+    static_assert(LA >= 4, "the wait-count formulas assume at least 4 rows of look-ahead");
+    static constexpr int NFRAG = 9 * KC * NCT;                      // weight fragments per wave
+    static constexpr int NFA_MAX = (256 - 16 * NCT) / 4;            // AGPR room beside the accumulators
+    static constexpr int NFA = NFRAG < NFA_MAX ? NFRAG : NFA_MAX;   // fragments pinned to AGPRs
+    static constexpr int LDS_BYTES = RING_BYTES + NWAVES * STAGE_BYTES;
+    // pipelined epilogue micro-steps (run between the MFMAs of the NEXT row): 1 residual wait,
+    // then 6 per store group (LDS read, 4 x two channels, pack + store)
+    static constexpr int NSTEP = OUT_F32 ? 0 : 1 + 6 * NST;
+    static constexpr int NMFMA = 9 * KC * NCT;
 };
+
+template <int V>
+struct IntC { static constexpr int value = V; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(IntC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// ---- LDS traffic is written as asm so that the waits can be COUNTED (the compiler waits
+// lgkmcnt(0) in front of an asm consumer).  LDS operations of a wave complete in issue order, so
+// "all but the N youngest" is exact for them whatever scalar loads the compiler has in flight.
+template <int OFFSET>
+__device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr)
+{
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFFSET));
+    return r;
+}
+__device__ __forceinline__ f32x4 lds_read_f32x4(unsigned addr)
+{
+    f32x4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+// accumulator quad (AGPRs) straight to LDS: no copy through VGPRs
+__device__ __forceinline__ void lds_write_acc_quad(unsigned addr, const f32x4& q)
+{
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "a"(q) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+}
+
+// One MFMA with the weight fragment pinned to an AGPR (IN_AGPR) or a VGPR.  Written as asm: the
+// builtin lets the register allocator park weights in AGPRs and copy them back (4 moves per MFMA).
+// FIRST: start of an accumulation chain, C = 0 (inline constant), so no accumulator init exists.
+template <bool IN_AGPR, bool FIRST>
+__device__ __forceinline__ void mfma_pinned(f32x16& acc, const bf16x8& w, const bf16x8& b)
+{
+    if constexpr (IN_AGPR) {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(b));
+    } else {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(b));
+    }
+}
+
+// Vector-memory operations (LDS-DMA loads, residual loads, output stores) retire in issue order
+// on one counter.  All of them are issued unconditionally (out-of-range lanes are dropped by the
+// buffer bounds check, never by a branch), so "all but the N youngest" names exact operations.
+template <int N>
+__device__ __forceinline__ void vm_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+// Raw buffer descriptor (stride 0, bounds-checked against `bytes`) for asm buffer loads.
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 d;
+    d[0] = (int)(unsigned)(a & 0xffffffffull);
+    d[1] = (int)(unsigned)((a >> 32) & 0xffffull);
+    d[2] = (int)bytes;
+    d[3] = 0x00020000;
+    return d;
+}
+// Residual fetch hidden from the compiler's wait bookkeeping (it would drain the LDS-DMA queue).
+__device__ __forceinline__ u32x4 buffer_load_b128_async(const i32x4 srd, unsigned voffset)
+{
+    u32x4 r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voffset), "s"(srd));
+    return r;
+}
+constexpr unsigned kOobOffset = 0x80000000u;  // beyond every image: the bounds check drops the lane
 
 template <class C>
 __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvParams p)
@@ -67,38 +194,72 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
     const int pg = wave / C::CSPLIT;  // which 32-pixel group of the row
     const int hl = lane >> 5;         // k half of the MFMA fragment / cout sub-block
     const int pl = lane & 31;         // pixel within the group
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     // ---- weights -> registers (fragment order prepared by the pack kernel) ----
     bf16x8 wreg[9][C::KC][C::NCT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int kc = 0; kc < C::KC; ++kc)
 #pragma unroll
             for (int ct = 0; ct < C::NCT; ++ct)
                 wreg[t][kc][ct] = p.wpack[((t * C::KC + kc) * C::CT_TOTAL + cs * C::NCT + ct) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);  // bound the registers the loads have in flight
+    }
 
-    // ---- bias -> registers, in accumulator order: reg r <-> cout = tile*32 + 8*(r>>2) + 4*hl + (r&3)
-    float breg[C::NCT][16];
+    // ---- epilogue lane roles (bf16 NHWC output).  Store time is pixel-major: lane = (pixel st_q of
+    // a group of PPI pixels, 8-channel chunk st_c), so this lane always owns the same 8 channels.
+    const int st_q = lane / C::LPP;
+    const int st_c = lane % C::LPP;
+    const int st_fw = C::NCT == 2 ? (pl & 15) : ((pl >> 1) & 7);  // slot swizzle of the pixel this lane stages
+    const unsigned stage_lds = lds_base + C::RING_BYTES + wave * C::STAGE_BYTES;
+    // staging write address of accumulator quad (ct, g): wst ^ ((ct*8 + 2g) << 4)
+    const unsigned wst = stage_lds + pl * C::PXS + (((hl ^ st_fw) & (C::NSLOT - 1)) << 4);
+    // staging read address of store group k: low half rdst[k], high half rdst[k] ^ 16
+    unsigned rdst[C::NST];
 #pragma unroll
-    for (int ct = 0; ct < C::NCT; ++ct)
+    for (int k = 0; k < C::NST; ++k) {
+        const int q = k * C::PPI + st_q;
+        const int fq = C::NCT == 2 ? (q & 15) : ((q >> 1) & 7);
+        rdst[k] = stage_lds + q * C::PXS + ((((2 * st_c) ^ fq) & (C::NSLOT - 1)) << 4);
+    }
+
+    // ---- bias -> registers.  bf16 NHWC: alpha * bias of this lane's 8 store-time channels;
+    // fp32 NCHW: accumulator order, reg r <-> cout = tile*32 + 8*(r>>2) + 4*hl + (r&3).
+    constexpr int NBIAS = C::OUT_F32 ? 16 * C::NCT : 8;
+    float breg[NBIAS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (cs * C::NCT + ct) * 32 + 8 * (r >> 2) + 4 * hl + (r & 3);
-            breg[ct][r] = (p.bias != nullptr && co < p.cout) ? p.bias[co] : 0.0f;
-        }
+    for (int r = 0; r < NBIAS; ++r) {
+        const int co = C::OUT_F32 ? (cs * C::NCT + r / 16) * 32 + 8 * ((r & 15) >> 2) + 4 * hl + (r & 3)
+                                  : cs * C::NCT * 32 + st_c * 8 + r;
+        const float b = (p.bias != nullptr && co < p.cout) ? p.bias[co] : 0.0f;
+        breg[r] = C::OUT_F32 ? b : b * p.alpha;
+    }
 
     // ---- per-lane LDS read offsets inside a row slot, one per horizontal tap ----
-    int rd[3];
+    unsigned rd[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int px = 32 * pg + pl + kx;
-        rd[kx] = px * 32 + (((hl ^ (px >> 3)) & 1) << 4);
+        rd[kx] = (unsigned)(px * 32 + (((hl ^ (px >> 3)) & 1) << 4));
     }
+
+    // LDS-DMA pieces this wave issues per row (wave-uniform): MAXP or MAXP - 1
+    const int my_pieces = (C::NPIECE - wave + C::NWAVES - 1) / C::NWAVES;
 
     const int H = p.h, W = p.w;
     const long long row_a_bytes = (long long)W * p.ca * 2;
     const long long row_b_bytes = (long long)W * p.cb * 2;
+
+    // pixel fragments, double buffered over taps; the buffer of (row i, tap t) is (i + t) & 1
+    bf16x8 bq[2][C::KC];
+    f32x16 acc[C::NCT];
+    // residual of row i lives in resv[i & 1]
+    u32x4 resv[2][C::NRES > 0 ? C::NRES : 1];
+    // epilogue scratch carried between micro-steps
+    f32x4 e_lo, e_hi;
+    float ev[8];
 
     for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
         const int strip = item % p.nstrips;
@@ -132,12 +293,29 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             pflag[m] = (part ? 1 : 0) | (xin ? 2 : 0) | (is_b ? 4 : 0);
         }
 
+        // per-image buffer descriptors: every output / residual access is bounds-checked by the
+        // hardware, which is how out-of-range lanes are dropped without a branch
+        const unsigned plane_bytes = (unsigned)(H * W) * 4u;
+        const unsigned img_bytes = C::OUT_F32 ? (unsigned)p.cout * plane_bytes : (unsigned)(H * W) * (unsigned)p.cout_stride * 2u;
+        const __amdgpu_buffer_rsrc_t dst_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)n * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const i32x4 res_srd = make_srd(C::HAS_RES ? p.res + (long long)n * img_bytes : p.dst, C::HAS_RES ? img_bytes : 0u);
+        const int xpix = x0 + 32 * pg + pl;
+
+        // byte offset (inside image n) of the 16 bytes this lane stores for pixel group k of row yy
+        auto out_offset = [&](int k, int yy, bool row_ok) -> unsigned {
+            const int xq = x0 + 32 * pg + k * C::PPI + st_q;
+            const int ch = cs * C::NCT * 32 + st_c * 8;
+            return (row_ok && xq < W && ch < p.cout_stride) ? (unsigned)(((yy * W + xq) * p.cout_stride + ch) * 2)
+                                                            : kOobOffset;
+        };
+
         auto issue_row = [&](int r) {
             const int y = y0 - 1 + r;
-            const bool yin = (y >= 0) && (y < H);
+            const bool yin = (y >= 0) && (y < H) && (r < nin);
             const char* row_a = p.src_a + ((long long)n * H + y) * row_a_bytes;
             const char* row_b = p.src_b + ((long long)n * H + y) * row_b_bytes;
-            char* slot = smem + (r & (C::RING - 1)) * C::SLOT_BYTES;
+            char* slot = smem + (r % C::RING) * C::SLOT_BYTES;
 #pragma unroll
             for (int m = 0; m < C::MAXP; ++m) {
                 const int q = wave + m * C::NWAVES;
@@ -151,91 +329,183 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             }
         };
 
-        __syncthreads();  // every wave is done reading the previous item's rows
-#pragma unroll 1
-        for (int r = 0; r < C::LA && r < nin; ++r) issue_row(r);
-
-#pragma unroll 1
-        for (int i = 0; i < nout; ++i) {
-            // rows i..i+2 were issued at least one iteration ago; wait for this wave's pieces,
-            // then the barrier makes every wave's pieces visible (and frees row i-1's slot).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (i + C::LA < nin) issue_row(i + C::LA);
-
-            f32x16 acc[C::NCT];
+        // ---- one micro-step of the second epilogue half (staging -> registers -> HBM) of the row
+        // whose residual is in resv[AP]; output row yy (row_ok false: every store is dropped).
+        auto epi_step = [&](auto step_c, auto ap_c, const int yy, const bool row_ok) {
+            constexpr int S = decltype(step_c)::value;
+            constexpr int AP = decltype(ap_c)::value;
+            if constexpr (S == 0) {
+                if constexpr (C::HAS_RES) {
+                    if (my_pieces == C::MAXP) vm_wait<C::res_wait(C::MAXP)>();
+                    else vm_wait<C::res_wait(C::MAXP - 1)>();
 #pragma unroll
-            for (int ct = 0; ct < C::NCT; ++ct)
+                    for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));  // consumers stay behind the wait
+                }
+            } else {
+                constexpr int j = S - 1;
+                constexpr int k = j / 6, st = j % 6;
+                if constexpr (st == 0) {
+                    e_lo = lds_read_f32x4(rdst[k]);
+                    e_hi = lds_read_f32x4(rdst[k] ^ 16u);
+                    lds_wait<0>();
+                    asm volatile("" : "+v"(e_lo), "+v"(e_hi));  // consumers stay behind the wait
+                } else if constexpr (st <= 4) {
+                    // two channels: alpha * act(x + bias) (+ residual); act(t) = max(t, slope * t)
+                    constexpr int e0 = 2 * (st - 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] = breg[ct][r];
-
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const char* rowp = smem + ((i + ky) & (C::RING - 1)) * C::SLOT_BYTES;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const char* ap = rowp + rd[kx];
-#pragma unroll
-                    for (int kc = 0; kc < C::KC; ++kc) {
-                        const bf16x8 b = *(const bf16x8*)(ap + kc * C::PLANE_BYTES);
-#pragma unroll
-                        for (int ct = 0; ct < C::NCT; ++ct)
-                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ky * 3 + kx][kc][ct], b,
-                                                                              acc[ct], 0, 0, 0);
+                    for (int e = e0; e < e0 + 2; ++e) {
+                        const float x = e < 4 ? e_lo[e & 3] : e_hi[e & 3];
+                        const float t = fmaf(x, p.alpha, breg[e]);
+                        float v = fmaxf(t, t * p.slope);
+                        if constexpr (C::HAS_RES) {
+                            const unsigned rr = resv[AP][k][e >> 1];
+                            v += (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
+                        }
+                        ev[e] = v;
                     }
+                } else {
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, out_offset(k, yy, row_ok), 0, 0);
+                }
+            }
+        };
+
+        // One output row.  PAR = i & 1 selects the fragment buffer that holds tap 0, the
+        // accumulator set and the residual set of this row.
+        auto row_body = [&](auto par_c, const int i) {
+            constexpr int PAR = decltype(par_c)::value;
+            // Input rows i..i+2 must have landed: wait until only operations younger than this wave's
+            // pieces of row i+2 are outstanding, then the barrier covers the other waves' pieces (and
+            // tells everyone that row i-1's slot is free).
+            if (i == 0) {
+                vm_wait<0>();
+            } else if (i < C::LA - 2) {
+                if (my_pieces == C::MAXP) vm_wait<C::top_wait_early(C::MAXP)>();
+                else vm_wait<C::top_wait_early(C::MAXP - 1)>();
+            } else {
+                if (my_pieces == C::MAXP) vm_wait<C::top_wait_steady(C::MAXP)>();
+                else vm_wait<C::top_wait_steady(C::MAXP - 1)>();
+            }
+            __builtin_amdgcn_s_barrier();
+
+            const int y = y0 + i;
+            if constexpr (C::HAS_RES) {
+#pragma unroll
+                for (int k = 0; k < C::NST; ++k) resv[PAR][k] = buffer_load_b128_async(res_srd, out_offset(k, y, true));
+            }
+            issue_row(i + C::LA);  // always the same number of operations (rows past the item read zeros)
+
+            unsigned rowa[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) rowa[ky] = lds_base + ((i + ky) % C::RING) * C::SLOT_BYTES;
+
+            if constexpr (PAR == 0) {
+                if (i == 0) {  // first row of the item: nobody fetched its tap 0 yet
+                    const unsigned a0 = rowa[0] + rd[0];
+                    if constexpr (C::KC > 0) bq[0][0] = lds_read_b128<0 * C::PLANE_BYTES>(a0);
+                    if constexpr (C::KC > 1) bq[0][1] = lds_read_b128<1 * C::PLANE_BYTES>(a0);
+                    if constexpr (C::KC > 2) bq[0][2] = lds_read_b128<2 * C::PLANE_BYTES>(a0);
+                    if constexpr (C::KC > 3) bq[0][3] = lds_read_b128<3 * C::PLANE_BYTES>(a0);
+                    if constexpr (C::KC > 4) bq[0][4] = lds_read_b128<4 * C::PLANE_BYTES>(a0);
+                    if constexpr (C::KC > 5) bq[0][5] = lds_read_b128<5 * C::PLANE_BYTES>(a0);
                 }
             }
 
-            // ---- epilogue ----
-            const int x = x0 + 32 * pg + pl;
-            const int y = y0 + i;
-            if (x < W) {
-                if (!p.dst_nchw_f32) {
-                    const long long pix = ((long long)n * H + y) * W + x;
-                    char* drow = p.dst + pix * p.cout_stride * 2;
-                    const char* rrow = p.res ? p.res + pix * p.cout_stride * 2 : nullptr;
-#pragma unroll
-                    for (int ct = 0; ct < C::NCT; ++ct)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int c0 = (cs * C::NCT + ct) * 32 + 8 * g + 4 * hl;
-                            if (c0 < p.cout_stride) {
-                                float v[4];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    float t = acc[ct][4 * g + e];
-                                    if (p.act == SRHIP_ACT_RELU) t = fmaxf(t, 0.0f);
-                                    else if (p.act == SRHIP_ACT_LRELU) t = t > 0.0f ? t : t * p.slope;
-                                    v[e] = t * p.alpha;
-                                }
-                                if (rrow) {
-                                    const uint2 rr = *(const uint2*)(rrow + c0 * 2);
-                                    v[0] += bf16_lo(rr.x); v[1] += bf16_hi(rr.x);
-                                    v[2] += bf16_lo(rr.y); v[3] += bf16_hi(rr.y);
-                                }
-                                uint2 o;
-                                o.x = pack_bf16x2(v[0], v[1]);
-                                o.y = pack_bf16x2(v[2], v[3]);
-                                *(uint2*)(drow + c0 * 2) = o;
-                            }
-                        }
+            // Pixel fragments run one tap ahead of the MFMAs: while tap t multiplies, the KC fragments
+            // of tap t+1 (or of tap 0 of the NEXT row, whose LDS row is already resident) are in
+            // flight.  Between the MFMAs run the epilogue micro-steps of the PREVIOUS row.
+            static_for<0, 9>([&](auto t_c) {
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;                  // tap being fetched
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;  // its LDS row relative to input row i
+                if (t < 8 || i + 1 < nout) {
+                    const unsigned an = rowa[kyn] + rd[tn % 3];
+                    if constexpr (C::KC > 0) bq[nxt][0] = lds_read_b128<0 * C::PLANE_BYTES>(an);
+                    if constexpr (C::KC > 1) bq[nxt][1] = lds_read_b128<1 * C::PLANE_BYTES>(an);
+                    if constexpr (C::KC > 2) bq[nxt][2] = lds_read_b128<2 * C::PLANE_BYTES>(an);
+                    if constexpr (C::KC > 3) bq[nxt][3] = lds_read_b128<3 * C::PLANE_BYTES>(an);
+                    if constexpr (C::KC > 4) bq[nxt][4] = lds_read_b128<4 * C::PLANE_BYTES>(an);
+                    if constexpr (C::KC > 5) bq[nxt][5] = lds_read_b128<5 * C::PLANE_BYTES>(an);
+                    lds_wait<C::KC>();
                 } else {
-                    // fp32 NCHW output (network output / fp32-accumulate checks)
-                    float* d = (float*)p.dst;
-#pragma unroll
-                    for (int ct = 0; ct < C::NCT; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int co = (cs * C::NCT + ct) * 32 + 8 * (r >> 2) + 4 * hl + (r & 3);
-                            if (co < p.cout) {
-                                float t = acc[ct][r];
-                                if (p.act == SRHIP_ACT_RELU) t = fmaxf(t, 0.0f);
-                                else if (p.act == SRHIP_ACT_LRELU) t = t > 0.0f ? t : t * p.slope;
-                                d[(((long long)n * p.cout + co) * H + y) * W + x] = t * p.alpha;
-                            }
-                        }
+                    lds_wait<0>();
                 }
+                static_for<0, C::KC * C::NCT>([&](auto m_c) {
+                    constexpr int ml = decltype(m_c)::value;
+                    constexpr int kc = ml / C::NCT, ct = ml % C::NCT;
+                    constexpr int f = (t * C::KC + kc) * C::NCT + ct;  // global MFMA index of the row
+                    mfma_pinned<(f < C::NFA), (t == 0 && kc == 0)>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
+                    if constexpr (!C::OUT_F32) {
+                        // epilogue steps [f*NSTEP/NMFMA, (f+1)*NSTEP/NMFMA) of the previous row
+                        constexpr int s0 = f * C::NSTEP / C::NMFMA, s1 = (f + 1) * C::NSTEP / C::NMFMA;
+                        static_for<s0, s1>([&](auto s_c) { epi_step(s_c, IntC<PAR ^ 1>{}, y - 1, i > 0); });
+                        __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
+                    }
+                });
+            });
+
+            // MFMA result -> any other reader: the hazard is invisible to the compiler inside asm
+            if constexpr (C::NCT == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]));
+            else asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]));
+            if constexpr (!C::OUT_F32) {
+                // first epilogue half: accumulator quads (ct, g) = channels 8g+4hl..+3 of pixel pl go
+                // straight from AGPRs to this wave's staging area; the rest of the epilogue runs
+                // between the MFMAs of the next row.
+                static_for<0, 4 * C::NCT>([&](auto s_c) {
+                    constexpr int S = decltype(s_c)::value;
+                    constexpr int ct = S / 4, g = S % 4;
+                    const f32x4 q = __builtin_shufflevector(acc[ct], acc[ct], 4 * g, 4 * g + 1, 4 * g + 2, 4 * g + 3);
+                    lds_write_acc_quad(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), q);
+                });
+            } else {
+                // fp32 NCHW output (network output / fp32-accumulate checks): plain epilogue.
+                const unsigned pixoff = (unsigned)((y * W + xpix) * 4);
+#pragma unroll
+                for (int ct = 0; ct < C::NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = (cs * C::NCT + ct) * 32 + 8 * (r >> 2) + 4 * hl + (r & 3);
+                        const float t = acc[ct][r] + breg[ct * 16 + r];
+                        const float v = fmaxf(t, t * p.slope) * p.alpha;
+                        const unsigned vo = (xpix < W && co < p.cout) ? (unsigned)co * plane_bytes + pixoff : kOobOffset;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst_rsrc, vo, 0, 0);
+                    }
             }
+        };
+
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the previous item's rows
+#pragma unroll 1
+        for (int r = 0; r < C::LA; ++r) issue_row(r);
+
+#pragma unroll 1
+        for (int i = 0; i < nout; i += 2) {
+            row_body(IntC<0>{}, i);
+            if (i + 1 < nout) row_body(IntC<1>{}, i + 1);
+        }
+
+        if constexpr (!C::OUT_F32) {
+            // drain: second epilogue half of the last row
+            auto tail = [&](auto ap_c) {
+                constexpr int AP = decltype(ap_c)::value;
+                static_for<0, C::NSTEP>([&](auto s_c) {
+                    constexpr int S = decltype(s_c)::value;
+                    if constexpr (S == 0) {
+                        if constexpr (C::HAS_RES) {
+                            if (my_pieces == C::MAXP) vm_wait<C::res_wait_tail(C::MAXP)>();
+                            else vm_wait<C::res_wait_tail(C::MAXP - 1)>();
+#pragma unroll
+                            for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));
+                        }
+                    } else {
+                        epi_step(s_c, ap_c, y1 - 1, true);
+                    }
+                });
+            };
+            if ((nout - 1) & 1) tail(IntC<1>{});
+            else tail(IntC<0>{});
         }
     }
 }
@@ -364,6 +634,8 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     SRHIP_REQUIRE(a->ca > 0 && a->ca % 16 == 0 && a->cb >= 0 && a->cb % 16 == 0, "conv3x3: channels must be multiples of 16 (ca=%d cb=%d)", a->ca, a->cb);
     SRHIP_REQUIRE((a->cb == 0) == (a->src_b == nullptr), "conv3x3: src_b and cb disagree");
     SRHIP_REQUIRE(a->cout >= 1 && a->cout <= 64, "conv3x3: cout %d not in [1,64]", a->cout);
+    SRHIP_REQUIRE(a->act == SRHIP_ACT_NONE || a->act == SRHIP_ACT_RELU || a->act == SRHIP_ACT_LRELU, "conv3x3: bad activation %d", a->act);
+    SRHIP_REQUIRE((long long)a->h * a->w * 64 * 4 < (1ll << 31), "conv3x3: image too large for 32-bit offsets");
     SRHIP_REQUIRE((long long)a->w * (a->ca > a->cb ? a->ca : a->cb) * 2 < (1ll << 31), "conv3x3: row too long");
     if (a->dst_nchw_f32) {
         SRHIP_REQUIRE(a->res == nullptr, "conv3x3: fp32 NCHW output takes no residual");
@@ -383,13 +655,18 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     p.n = a->n; p.h = a->h; p.w = a->w;
     p.ca = a->ca; p.cb = a->cb; p.kc_a = a->ca / 16;
     p.cout = a->cout; p.cout_stride = a->cout_stride;
-    p.act = a->act; p.slope = a->slope; p.alpha = a->alpha;
+    p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
+    p.alpha = a->alpha;
     p.dst_nchw_f32 = a->dst_nchw_f32;
     const int kc = (a->ca + a->cb) / 16;
     const int ct = (a->cout + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
-#define SRHIP_CONV_CASE(KC, CT, CSPLIT) \
-    if (kc == KC && ct == CT) return launch_conv<Cfg<KC, CT, CSPLIT>>(p, s);
+#define SRHIP_CONV_CASE(KC, CT, CSPLIT)                                                                 \
+    if (kc == KC && ct == CT) {                                                                         \
+        if (a->dst_nchw_f32) return launch_conv<Cfg<KC, CT, CSPLIT, true, false>>(p, s);                \
+        if (a->res != nullptr) return launch_conv<Cfg<KC, CT, CSPLIT, false, true>>(p, s);              \
+        return launch_conv<Cfg<KC, CT, CSPLIT, false, false>>(p, s);                                    \
+    }
     SRHIP_CONV_CASE(1, 1, 1)
     SRHIP_CONV_CASE(2, 1, 1)
     SRHIP_CONV_CASE(3, 1, 1)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the 3x3 MFMA convolution at 4K (dev helper, run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from superresolution_amd import functional as F_
+
+H, W = 2160, 3840
+dev = torch.device("cuda")
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def case(name, ca, cb, cout, res=False, f32=False, act=1, alpha=1.0, h=H, w=W, n=1):
+    xa = (torch.rand(n, h, w, ca, device=dev) - 0.5).to(torch.bfloat16)
+    xb = (torch.rand(n, h, w, cb, device=dev) - 0.5).to(torch.bfloat16) if cb else None
+    wt = torch.randn(cout, ca + cb, 3, 3, device=dev) * 0.05
+    b = torch.randn(cout, device=dev) * 0.1
+    wp = F_.conv3x3_pack_weights(wt, ca, ca, cb, cb)
+    r = (torch.rand(n, h, w, F_.pad16(cout), device=dev) - 0.5).to(torch.bfloat16) if res else None
+    out = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev) if f32 else torch.empty((n, h, w, F_.pad16(cout)), dtype=torch.bfloat16, device=dev)
+    fn = lambda: F_.conv3x3(xa, wp, b, cout, src_b=xb, res=r, act=act, alpha=alpha, out_nchw_f32=f32, out=out)
+    med, best = timeit(fn)
+    flop = 2.0 * n * h * w * cout * (ca + cb) * 9
+    byts = n * h * w * ((ca + cb) * 2 + (cout * 4 if f32 else F_.pad16(cout) * 2) + (F_.pad16(cout) * 2 if res else 0))
+    print(f"{name:28s} median {med:7.3f} ms  best {best:7.3f} ms  {flop / med / 1e9:8.1f} TFLOP/s  {byts / med / 1e6:7.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "quick":
+        case("64->64 relu", 64, 0, 64)
+        case("16->64 relu", 16, 0, 64)
+        case("64->3 f32 nchw", 64, 0, 3, f32=True, act=0)
+        sys.exit(0)
+    case("64->64 relu", 64, 0, 64)
+    case("64->64 0.2*conv+res", 64, 0, 64, res=True, act=0, alpha=0.2)
+    case("(32+64)->64 relu", 32, 64, 64)
+    case("16->64 relu", 16, 0, 64)
+    case("64->3 f32 nchw", 64, 0, 3, f32=True, act=0)
+    case("16->32 relu LR", 16, 0, 32, h=540, w=960)
+    case("32->32 relu LR", 32, 0, 32, h=540, w=960)
+    case("64->64 relu 16x1024^2", 64, 0, 64, h=1024, w=1024, n=16)
