@@ -8,20 +8,23 @@
 //     unified 512-entry file at one wave per SIMD holds the 288 registers of a 64->64 layer), so
 //     LDS carries only activations.
 //   * A workgroup walks a vertical strip of TW output columns top to bottom.  Input rows stream
-//     HBM -> LDS through a ring of RING rows filled by global_load_lds (LDS-DMA, 16 B per lane),
-//     LA rows ahead of the row being computed; every input row is fetched once per strip.  One
-//     wave = 32 consecutive pixels of the current row.
-//   * LDS row image: [16-channel plane][pixel][32 B]; the two 16-B halves of a pixel are swapped
-//     when (pixel >> 3) & 1, which makes the ds_read_b128 of 32 consecutive pixels conflict free.
-//     LDS-DMA writes linearly, so the swap is applied to the per-lane SOURCE address.
-//   * Channel concat of two source tensors is folded into the K loop (planes of A then planes of B).
+//     HBM -> LDS through a ring of RING rows filled by LDS-DMA (buffer_load ... lds, 16 B per lane),
+//     LA rows ahead of the row being computed; every input row is fetched once per strip.  Lanes
+//     whose pixel lies outside the image fail the buffer bounds check and the DMA writes zeros for
+//     them: that IS the zero padding, and no address arithmetic runs per row (the row enters
+//     through the scalar offset of the instruction).  One wave = 32 consecutive pixels of a row.
+//   * LDS row image: one pixel-major sub-image per group of 16/32/64 channels, [pixel][16-B chunk]
+//     with the chunk index XOR-swizzled by the pixel index so that the ds_read_b128 of 32
+//     consecutive pixels is conflict free; each 1-KiB DMA piece covers whole (sub-)pixels, i.e.
+//     full lines of the source tensor.  LDS-DMA writes linearly, so the swizzle is applied to the
+//     per-lane SOURCE offset.  The channel concat of two source tensors = two sub-images.
 //   * All waits are COUNTED (s_waitcnt vmcnt(N) / lgkmcnt(N) written by hand): every vector-memory
 //     operation is issued unconditionally (out-of-range lanes are dropped by buffer bounds checks),
 //     so the number of younger operations at each wait is a compile-time constant.
-//   * The epilogue of row i-1 (accumulators -> LDS -> pixel-major: bias, activation, scale,
-//     residual, bf16 pack, 16-byte whole-pixel stores) is sliced into micro-steps that are
-//     interleaved with the MFMAs of row i (two accumulator sets), so vector ALU work hides in the
-//     matrix pipe's shadow.
+//   * Epilogue: accumulators go AGPR -> LDS (fp32) right after the row's MFMAs; the rest (pixel-
+//     major read back, bias, activation, scale, residual, bf16 pack, 16-byte whole-pixel stores)
+//     and all per-row issue work (LDS-DMA pieces, residual loads) are micro-steps interleaved with
+//     the MFMAs of the NEXT row, so they hide in the matrix pipe's shadow.
 #include "srhip_common.h"
 
 namespace {
@@ -33,15 +36,24 @@ struct ConvParams {
     const float* bias;
     const char* res;
     char* dst;
-    const char* zeros;
     int n, h, w;
     int ca, cb;  // padded channels of the two sources
-    int kc_a;    // 16-channel planes that come from src_a
     int cout, cout_stride;
     float slope, alpha;  // slope: 1 (no activation), 0 (ReLU) or the LeakyReLU slope
-    int dst_nchw_f32;
     int nstrips, nsegs, seg_h, total_items;
 };
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Channel groups (sub-images) of the K dimension, by number of 16-channel planes.
+//   KC = 3: one 48-channel tensor as 32 + 16;  KC = 6: concat of a 32-channel and a 64-channel tensor.
+template <int KC> struct SubLayout;
+template <> struct SubLayout<1> { static constexpr int NSUB = 1; static constexpr int CS0 = 16, CS1 = 0; };
+template <> struct SubLayout<2> { static constexpr int NSUB = 1; static constexpr int CS0 = 32, CS1 = 0; };
+template <> struct SubLayout<3> { static constexpr int NSUB = 2; static constexpr int CS0 = 32, CS1 = 16; };
+template <> struct SubLayout<4> { static constexpr int NSUB = 1; static constexpr int CS0 = 64, CS1 = 0; };
+template <> struct SubLayout<6> { static constexpr int NSUB = 2; static constexpr int CS0 = 32, CS1 = 64; };
 
 template <int KC_, int CT_TOTAL_, int CSPLIT_, bool OUT_F32_, bool HAS_RES_>
 struct Cfg {
@@ -54,17 +66,27 @@ struct Cfg {
     static constexpr int NWAVES = 4;
     static constexpr int NPG = NWAVES / CSPLIT;  // pixel groups (32 px) per row
     static constexpr int TW = 32 * NPG;          // strip width
-    static constexpr int PW = (TW + 2 + 7) / 8 * 8;  // LDS row pitch in pixels (1 halo px each side)
-    static constexpr int PLANE_BYTES = PW * 32;
-    static constexpr int SLOT_BYTES = KC * PLANE_BYTES;
-    static constexpr int SLOT_CHUNKS = SLOT_BYTES / 16;
-    static constexpr int NPIECE = (SLOT_CHUNKS + 63) / 64;          // 1 KiB LDS-DMA pieces per row
+    // ---- LDS row image: sub-image s holds CS_s channels of every pixel, pixel-major ----
+    using SL = SubLayout<KC>;
+    static constexpr int NSUB = SL::NSUB;
+    static constexpr int cs(int s) { return s == 0 ? SL::CS0 : SL::CS1; }       // channels
+    static constexpr int cpp(int s) { return cs(s) / 8; }                        // 16-B chunks per pixel
+    static constexpr int lcpp(int s) { return cpp(s) == 8 ? 3 : (cpp(s) == 4 ? 2 : 1); }
+    static constexpr int pw(int s) { return round_up(TW + 2, 64 / cpp(s)); }     // pitch: whole 1-KiB pieces
+    static constexpr int sub_bytes(int s) { return pw(s) * cs(s) * 2; }
+    static constexpr int sub_off(int s) { return s == 0 ? 0 : sub_bytes(0); }
+    static constexpr int sub_pieces(int s) { return sub_bytes(s) / 1024; }
+    static constexpr int piece_base(int s) { return s == 0 ? 0 : sub_pieces(0); }
+    static constexpr int sub_of(int kc) { return (NSUB == 2 && kc >= SL::CS0 / 16) ? 1 : 0; }
+    static constexpr int kcl_of(int kc) { return sub_of(kc) == 1 ? kc - SL::CS0 / 16 : kc; }
+    static constexpr int SLOT_BYTES = sub_bytes(0) + (NSUB == 2 ? sub_bytes(1) : 0);
+    static constexpr int NPIECE = SLOT_BYTES / 1024;                // 1 KiB LDS-DMA pieces per row
     static constexpr int MAXP = (NPIECE + NWAVES - 1) / NWAVES;     // pieces per wave per row
     static constexpr int LA = 5;                                    // rows issued ahead of the row being computed
     static constexpr int RING = LA + 1;                             // LDS row slots
     static constexpr int RING_BYTES = RING * SLOT_BYTES;
-    // Epilogue staging (bf16 NHWC output): the wave's 32 px x (32*NCT) fp32 results cross LDS once so
-    // that every store instruction writes whole pixels (16 B per lane, 1 KiB contiguous per wave).
+    // ---- epilogue staging (bf16 NHWC output): the wave's 32 px x (32*NCT) fp32 results cross LDS
+    // once so that every store instruction writes whole pixels (16 B per lane, 1 KiB per wave).
     static constexpr int NSLOT = 8 * NCT;                           // 16-B fp32 slots per staged pixel
     static constexpr int PXS = NSLOT * 16;                          // staged bytes per pixel
     static constexpr int LPP = NSLOT / 2;                           // lanes per pixel at store time (8 ch each)
@@ -73,7 +95,7 @@ struct Cfg {
     static constexpr int STAGE_BYTES = OUT_F32 ? 0 : 32 * PXS;      // per wave
     static constexpr int NSTORE = OUT_F32 ? 16 * NCT : NST;         // store instructions per wave per row
     static constexpr int NRES = HAS_RES ? NST : 0;                  // residual load instructions per wave per row
-    // Vector-memory operations one wave issues per iteration i, in order:
+    // ---- counted vector-memory waits.  One wave issues per iteration i, in this order:
     //   [residual loads of row i] [LDS-DMA pieces of row i+LA] [output stores of row i-1]
     // (fp32 NCHW output: stores of row i).  P = pieces of this wave (MAXP or MAXP-1).
     // Top of iteration i waits for input row i+2, issued at iteration i+2-LA: younger operations are
@@ -83,8 +105,8 @@ struct Cfg {
     // iterations 1 .. LA-3 of an item: the row was issued by the prologue; row 3's younger operations
     // at iteration 1 are the fewest and bound all of them.
     static constexpr int top_wait_early(int P) { return clamp63((LA - 4) * P + NRES + P + NSTORE); }
-    // Residual of row i-1 (loaded at the top of iteration i-1) is consumed in iteration i after the
-    // pieces of iteration i were issued: younger are pieces(i-1), stores(i-2), residual(i), pieces(i).
+    // Residual of row i-1 (loaded in iteration i-1) is consumed in iteration i after the pieces of
+    // iteration i were issued: younger are pieces(i-1), stores(i-2), residual(i), pieces(i).
     static constexpr int res_wait(int P) { return clamp63(2 * P + NSTORE + NRES); }
     // ... and after the row loop (last row): younger are that iteration's pieces and stores.
     static constexpr int res_wait_tail(int P) { return clamp63(P + NSTORE); }
@@ -93,11 +115,23 @@ struct Cfg {
     static constexpr int NFA_MAX = (256 - 16 * NCT) / 4;            // AGPR room beside the accumulators
     static constexpr int NFA = NFRAG < NFA_MAX ? NFRAG : NFA_MAX;   // fragments pinned to AGPRs
     static constexpr int LDS_BYTES = RING_BYTES + NWAVES * STAGE_BYTES;
-    // pipelined epilogue micro-steps (run between the MFMAs of the NEXT row): 1 residual wait,
-    // then 6 per store group (LDS read, 4 x two channels, pack + store)
-    static constexpr int NSTEP = OUT_F32 ? 0 : 1 + 6 * NST;
-    static constexpr int NMFMA = 9 * KC * NCT;
+    static constexpr int MPT = KC * NCT;                            // MFMAs per tap
+    // micro-steps run between the MFMAs of tap t (they belong to the PREVIOUS row's epilogue, except
+    // tap 0 which issues this row's residual loads and the LDS-DMA pieces of row i+LA):
+    //   tap 0: NRES + MAXP;  tap 2k+1: [residual wait] + channels 0..3 of store group k;
+    //   tap 2k+2: channels 4..7 + pack/store of group k.
+    static constexpr int tap_steps(int t) {
+        if (t == 0) return NRES + MAXP;
+        if (OUT_F32) return 0;
+        const int k = (t - 1) / 2;
+        if (k >= NST) return 0;
+        return (t & 1) ? 4 + ((k == 0 && HAS_RES) ? 1 : 0) : 5;
+    }
 };
+
+// Nested generic lambdas only capture what their own body odr-uses outside discarded branches;
+// naming a variable here makes every enclosing closure capture it.
+#define SRHIP_CAPTURE(x) (void)&(x)
 
 template <int V>
 struct IntC { static constexpr int value = V; };
@@ -116,11 +150,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // ---- LDS traffic is written as asm so that the waits can be COUNTED (the compiler waits
 // lgkmcnt(0) in front of an asm consumer).  LDS operations of a wave complete in issue order, so
 // "all but the N youngest" is exact for them whatever scalar loads the compiler has in flight.
-template <int OFFSET>
 __device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr)
 {
     bf16x8 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFFSET));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
     return r;
 }
 __device__ __forceinline__ f32x4 lds_read_f32x4(unsigned addr)
@@ -175,10 +208,18 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes)
     return d;
 }
 // Residual fetch hidden from the compiler's wait bookkeeping (it would drain the LDS-DMA queue).
-__device__ __forceinline__ u32x4 buffer_load_b128_async(const i32x4 srd, unsigned voffset)
+// The LDS-DMA builtin lives in a plain device function: called directly from a generic lambda it
+// makes the host pass drop the kernel's launch stub without a diagnostic.
+__device__ __forceinline__ void lds_dma_b128(__amdgpu_buffer_rsrc_t rsrc, __attribute__((address_space(3))) void* dst,
+                                             int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 0);
+}
+
+__device__ __forceinline__ u32x4 buffer_load_b128_async(const i32x4 srd, unsigned voffset, unsigned soffset)
 {
     u32x4 r;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voffset), "s"(srd));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voffset), "s"(srd), "s"(soffset));
     return r;
 }
 constexpr unsigned kOobOffset = 0x80000000u;  // beyond every image: the bounds check drops the lane
@@ -237,20 +278,25 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
         breg[r] = C::OUT_F32 ? b : b * p.alpha;
     }
 
-    // ---- per-lane LDS read offsets inside a row slot, one per horizontal tap ----
-    unsigned rd[3];
+    // ---- per-lane LDS read offsets inside a row slot: rd[kx][s] addresses chunk (hl) of LDS pixel
+    // 32pg + pl + kx in sub-image s; chunk pair kcl of the same pixel is at rd ^ (kcl << 5).
+    unsigned rd[3][C::NSUB];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        const int px = 32 * pg + pl + kx;
-        rd[kx] = (unsigned)(px * 32 + (((hl ^ (px >> 3)) & 1) << 4));
-    }
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int s = 0; s < C::NSUB; ++s) {
+            const int px = 32 * pg + pl + kx;
+            const int f = (px >> (4 - C::lcpp(s))) & (C::cpp(s) - 1);
+            rd[kx][s] = (unsigned)(C::sub_off(s) + px * C::cpp(s) * 16 + ((hl ^ f) << 4));
+        }
 
     // LDS-DMA pieces this wave issues per row (wave-uniform): MAXP or MAXP - 1
     const int my_pieces = (C::NPIECE - wave + C::NWAVES - 1) / C::NWAVES;
 
     const int H = p.h, W = p.w;
-    const long long row_a_bytes = (long long)W * p.ca * 2;
-    const long long row_b_bytes = (long long)W * p.cb * 2;
+    // source of sub-image s: KC == 6 is concat(A: 32 ch, B: 64 ch); KC == 3 is one 48-channel tensor
+    const int csrc0 = p.ca, csrc1 = (C::KC == 6) ? p.cb : p.ca;
+    const int choff1 = (C::KC == 3) ? 32 : 0;
 
     // pixel fragments, double buffered over taps; the buffer of (row i, tap t) is (i + t) & 1
     bf16x8 bq[2][C::KC];
@@ -272,108 +318,105 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
         const int nout = y1 - y0;
         const int nin = nout + 2;  // input rows r = 0..nin-1  <->  y = y0 - 1 + r
 
-        // ---- per-lane source offsets of this wave's LDS-DMA pieces (constant over the strip) ----
-        int poff[C::MAXP];
-        int pflag[C::MAXP];  // bit0: lane participates, bit1: x inside the image, bit2: source B
+        // ---- per-image buffer descriptors (bounds-checked: out-of-range lanes read zeros / are dropped)
+        const unsigned img_a = (unsigned)(H * W) * (unsigned)csrc0 * 2u;
+        const unsigned img_b = (unsigned)(H * W) * (unsigned)csrc1 * 2u;
+        const __amdgpu_buffer_rsrc_t rsrc_a =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.src_a + (long long)n * img_a), 0, (int)img_a, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((C::KC == 6 ? p.src_b : p.src_a) + (long long)n * img_b), 0, (int)img_b, 0x00020000);
+        const unsigned plane_bytes = (unsigned)(H * W) * 4u;
+        const unsigned img_out = C::OUT_F32 ? (unsigned)p.cout * plane_bytes : (unsigned)(H * W) * (unsigned)p.cout_stride * 2u;
+        const __amdgpu_buffer_rsrc_t dst_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)n * img_out, 0, (int)img_out, 0x00020000);
+        const i32x4 res_srd = make_srd(C::HAS_RES ? p.res + (long long)n * img_out : p.dst, C::HAS_RES ? img_out : 0u);
+        const unsigned out_pitch = (unsigned)W * (unsigned)p.cout_stride * 2u;  // bytes per output row (NHWC)
+        const int xpix = x0 + 32 * pg + pl;
+
+        // ---- per-lane source offsets of this wave's LDS-DMA pieces (constant over the strip).
+        // Piece q covers LDS chunks [64q, 64q+64) of the row slot = whole pixels of one sub-image.
+        unsigned poff[C::MAXP];
+        bool psub1[C::MAXP];  // wave-uniform: the piece belongs to sub-image 1
 #pragma unroll
         for (int m = 0; m < C::MAXP; ++m) {
             const int q = wave + m * C::NWAVES;
-            const int j = q * 64 + lane;
-            const bool part = (q < C::NPIECE) && (j < C::SLOT_CHUNKS);
-            const int plane = j / (2 * C::PW);
-            const int rem = j - plane * (2 * C::PW);
-            const int px = rem >> 1;
-            const int hf = (rem & 1) ^ ((px >> 3) & 1);
+            const bool s1 = (C::NSUB == 2) && (q >= C::piece_base(1));
+            const int j = (q - (s1 ? C::piece_base(1) : 0)) * 64 + lane;
+            const int lc = s1 ? C::lcpp(1) : C::lcpp(0);
+            const int px = j >> lc;
+            const int slot = j & ((1 << lc) - 1);
+            const int c = slot ^ ((px >> (4 - lc)) & ((1 << lc) - 1));
             const int x = x0 - 1 + px;
-            const bool xin = (x >= 0) && (x < W);
-            const bool is_b = plane >= p.kc_a;
-            const int off = is_b ? (x * p.cb + (plane - p.kc_a) * 16 + hf * 8) * 2
-                                 : (x * p.ca + plane * 16 + hf * 8) * 2;
-            poff[m] = off;
-            pflag[m] = (part ? 1 : 0) | (xin ? 2 : 0) | (is_b ? 4 : 0);
+            const bool ok = (x >= 0) && (x < W) && (px < C::TW + 2);
+            const int csrc = s1 ? csrc1 : csrc0;
+            const int choff = s1 ? choff1 : 0;
+            poff[m] = ok ? (unsigned)((x * csrc + choff + c * 8) * 2) : kOobOffset;
+            psub1[m] = s1;
         }
-
-        // per-image buffer descriptors: every output / residual access is bounds-checked by the
-        // hardware, which is how out-of-range lanes are dropped without a branch
-        const unsigned plane_bytes = (unsigned)(H * W) * 4u;
-        const unsigned img_bytes = C::OUT_F32 ? (unsigned)p.cout * plane_bytes : (unsigned)(H * W) * (unsigned)p.cout_stride * 2u;
-        const __amdgpu_buffer_rsrc_t dst_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)n * img_bytes, 0, (int)img_bytes, 0x00020000);
-        const i32x4 res_srd = make_srd(C::HAS_RES ? p.res + (long long)n * img_bytes : p.dst, C::HAS_RES ? img_bytes : 0u);
-        const int xpix = x0 + 32 * pg + pl;
-
-        // byte offset (inside image n) of the 16 bytes this lane stores for pixel group k of row yy
-        auto out_offset = [&](int k, int yy, bool row_ok) -> unsigned {
+        // per-lane output offsets inside a row (constant over the strip)
+        unsigned vox[C::NST];
+#pragma unroll
+        for (int k = 0; k < C::NST; ++k) {
             const int xq = x0 + 32 * pg + k * C::PPI + st_q;
             const int ch = cs * C::NCT * 32 + st_c * 8;
-            return (row_ok && xq < W && ch < p.cout_stride) ? (unsigned)(((yy * W + xq) * p.cout_stride + ch) * 2)
-                                                            : kOobOffset;
-        };
+            vox[k] = (xq < W && ch < p.cout_stride) ? (unsigned)((xq * p.cout_stride + ch) * 2) : kOobOffset;
+        }
 
-        auto issue_row = [&](int r) {
-            const int y = y0 - 1 + r;
-            const bool yin = (y >= 0) && (y < H) && (r < nin);
-            const char* row_a = p.src_a + ((long long)n * H + y) * row_a_bytes;
-            const char* row_b = p.src_b + ((long long)n * H + y) * row_b_bytes;
-            char* slot = smem + (r % C::RING) * C::SLOT_BYTES;
-#pragma unroll
-            for (int m = 0; m < C::MAXP; ++m) {
+        // LDS-DMA piece m of input row r (scalar row offsets; rows outside the image / item read zeros)
+        auto issue_piece = [&](auto m_c, const int r) {
+            constexpr int m = decltype(m_c)::value;
+            if (m < my_pieces) {
+                const int y = y0 - 1 + r;
+                const bool yin = (y >= 0) && (y < H) && (r < nin);
                 const int q = wave + m * C::NWAVES;
-                if (pflag[m] & 1) {
-                    const char* g = (pflag[m] & 4) ? row_b : row_a;
-                    g = (yin && (pflag[m] & 2)) ? g + poff[m] : p.zeros;
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)g,
-                        (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
-                }
+                auto* dst = (__attribute__((address_space(3))) void*)(smem + (r % C::RING) * C::SLOT_BYTES + q * 1024);
+                const bool from_b = psub1[m] && (C::KC == 6);
+                const unsigned soff = yin ? (unsigned)(y * W) * (unsigned)((psub1[m] ? csrc1 : csrc0) * 2) : kOobOffset;
+                if (from_b) lds_dma_b128(rsrc_b, dst, poff[m], soff);
+                else lds_dma_b128(rsrc_a, dst, poff[m], soff);
             }
         };
 
-        // ---- one micro-step of the second epilogue half (staging -> registers -> HBM) of the row
-        // whose residual is in resv[AP]; output row yy (row_ok false: every store is dropped).
-        auto epi_step = [&](auto step_c, auto ap_c, const int yy, const bool row_ok) {
-            constexpr int S = decltype(step_c)::value;
+        // ---- micro-steps of the second epilogue half of output row yy (staging -> HBM), whose
+        // residual is in resv[AP].  store_soff is the scalar row offset (kOobOffset drops the row).
+        auto epi_res_wait = [&](auto ap_c, auto tail_c) {
+            SRHIP_CAPTURE(resv);  // asm operands alone do not make a generic lambda capture
             constexpr int AP = decltype(ap_c)::value;
-            if constexpr (S == 0) {
-                if constexpr (C::HAS_RES) {
-                    if (my_pieces == C::MAXP) vm_wait<C::res_wait(C::MAXP)>();
-                    else vm_wait<C::res_wait(C::MAXP - 1)>();
+            constexpr bool TAIL = decltype(tail_c)::value != 0;
+            if constexpr (C::HAS_RES) {
+                if (my_pieces == C::MAXP) vm_wait<TAIL ? C::res_wait_tail(C::MAXP) : C::res_wait(C::MAXP)>();
+                else vm_wait<TAIL ? C::res_wait_tail(C::MAXP - 1) : C::res_wait(C::MAXP - 1)>();
 #pragma unroll
-                    for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));  // consumers stay behind the wait
-                }
-            } else {
-                constexpr int j = S - 1;
-                constexpr int k = j / 6, st = j % 6;
-                if constexpr (st == 0) {
-                    e_lo = lds_read_f32x4(rdst[k]);
-                    e_hi = lds_read_f32x4(rdst[k] ^ 16u);
-                    lds_wait<0>();
-                    asm volatile("" : "+v"(e_lo), "+v"(e_hi));  // consumers stay behind the wait
-                } else if constexpr (st <= 4) {
-                    // two channels: alpha * act(x + bias) (+ residual); act(t) = max(t, slope * t)
-                    constexpr int e0 = 2 * (st - 1);
-#pragma unroll
-                    for (int e = e0; e < e0 + 2; ++e) {
-                        const float x = e < 4 ? e_lo[e & 3] : e_hi[e & 3];
-                        const float t = fmaf(x, p.alpha, breg[e]);
-                        float v = fmaxf(t, t * p.slope);
-                        if constexpr (C::HAS_RES) {
-                            const unsigned rr = resv[AP][k][e >> 1];
-                            v += (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
-                        }
-                        ev[e] = v;
-                    }
-                } else {
-                    u32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
-                    __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, out_offset(k, yy, row_ok), 0, 0);
-                }
+                for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));  // consumers stay behind the wait
             }
         };
+        auto epi_read = [&](auto k_c) {  // staging reads of store group k (complete after the next LDS wait)
+            constexpr int k = decltype(k_c)::value;
+            e_lo = lds_read_f32x4(rdst[k]);
+            e_hi = lds_read_f32x4(rdst[k] ^ 16u);
+        };
+        auto epi_elem = [&](auto k_c, auto e_c, auto ap_c) {  // channel e: alpha * act(x + bias) (+ residual)
+            constexpr int k = decltype(k_c)::value;
+            constexpr int e = decltype(e_c)::value;
+            constexpr int AP = decltype(ap_c)::value;
+            const float x = e < 4 ? e_lo[e & 3] : e_hi[e & 3];
+            const float t = fmaf(x, p.alpha, breg[e]);
+            float v = fmaxf(t, t * p.slope);  // act(t) = max(t, slope * t), slope in {1, 0, s}
+            if constexpr (C::HAS_RES) {
+                const unsigned rr = resv[AP][k][e >> 1];
+                v += (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
+            }
+            ev[e] = v;
+        };
+        auto epi_store = [&](auto k_c, const unsigned store_soff) {
+            constexpr int k = decltype(k_c)::value;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
+            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);
+        };
 
-        // One output row.  PAR = i & 1 selects the fragment buffer that holds tap 0, the
-        // accumulator set and the residual set of this row.
+        // One output row.  PAR = i & 1 selects the fragment buffer that holds tap 0 and the residual set.
         auto row_body = [&](auto par_c, const int i) {
             constexpr int PAR = decltype(par_c)::value;
             // Input rows i..i+2 must have landed: wait until only operations younger than this wave's
@@ -391,59 +434,68 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             __builtin_amdgcn_s_barrier();
 
             const int y = y0 + i;
-            if constexpr (C::HAS_RES) {
-#pragma unroll
-                for (int k = 0; k < C::NST; ++k) resv[PAR][k] = buffer_load_b128_async(res_srd, out_offset(k, y, true));
-            }
-            issue_row(i + C::LA);  // always the same number of operations (rows past the item read zeros)
-
+            const unsigned res_soff = (unsigned)y * out_pitch;                       // residual of row i
+            const unsigned st_soff = i > 0 ? (unsigned)(y - 1) * out_pitch : kOobOffset;  // stores of row i-1
             unsigned rowa[3];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) rowa[ky] = lds_base + ((i + ky) % C::RING) * C::SLOT_BYTES;
 
             if constexpr (PAR == 0) {
                 if (i == 0) {  // first row of the item: nobody fetched its tap 0 yet
-                    const unsigned a0 = rowa[0] + rd[0];
-                    if constexpr (C::KC > 0) bq[0][0] = lds_read_b128<0 * C::PLANE_BYTES>(a0);
-                    if constexpr (C::KC > 1) bq[0][1] = lds_read_b128<1 * C::PLANE_BYTES>(a0);
-                    if constexpr (C::KC > 2) bq[0][2] = lds_read_b128<2 * C::PLANE_BYTES>(a0);
-                    if constexpr (C::KC > 3) bq[0][3] = lds_read_b128<3 * C::PLANE_BYTES>(a0);
-                    if constexpr (C::KC > 4) bq[0][4] = lds_read_b128<4 * C::PLANE_BYTES>(a0);
-                    if constexpr (C::KC > 5) bq[0][5] = lds_read_b128<5 * C::PLANE_BYTES>(a0);
+                    static_for<0, C::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[0][kc] = lds_read_b128((rowa[0] + rd[0][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));
+                    });
                 }
             }
 
             // Pixel fragments run one tap ahead of the MFMAs: while tap t multiplies, the KC fragments
             // of tap t+1 (or of tap 0 of the NEXT row, whose LDS row is already resident) are in
-            // flight.  Between the MFMAs run the epilogue micro-steps of the PREVIOUS row.
+            // flight.  Between the MFMAs run this tap's micro-steps.
             static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
                 constexpr int t = decltype(t_c)::value;
                 constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
                 constexpr int tn = (t + 1) % 9;                  // tap being fetched
                 constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;  // its LDS row relative to input row i
+                constexpr int KG = (t - 1) / 2;                  // store group served by taps 2k+1, 2k+2
+                constexpr bool EPI = !C::OUT_F32 && t >= 1 && KG < C::NST;
+                if constexpr (EPI && (t & 1)) epi_read(IntC<KG>{});
                 if (t < 8 || i + 1 < nout) {
-                    const unsigned an = rowa[kyn] + rd[tn % 3];
-                    if constexpr (C::KC > 0) bq[nxt][0] = lds_read_b128<0 * C::PLANE_BYTES>(an);
-                    if constexpr (C::KC > 1) bq[nxt][1] = lds_read_b128<1 * C::PLANE_BYTES>(an);
-                    if constexpr (C::KC > 2) bq[nxt][2] = lds_read_b128<2 * C::PLANE_BYTES>(an);
-                    if constexpr (C::KC > 3) bq[nxt][3] = lds_read_b128<3 * C::PLANE_BYTES>(an);
-                    if constexpr (C::KC > 4) bq[nxt][4] = lds_read_b128<4 * C::PLANE_BYTES>(an);
-                    if constexpr (C::KC > 5) bq[nxt][5] = lds_read_b128<5 * C::PLANE_BYTES>(an);
+                    static_for<0, C::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[nxt][kc] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));
+                    });
                     lds_wait<C::KC>();
                 } else {
                     lds_wait<0>();
                 }
-                static_for<0, C::KC * C::NCT>([&](auto m_c) {
+                if constexpr (EPI && (t & 1)) asm volatile("" : "+v"(e_lo), "+v"(e_hi));  // consumers stay behind the wait
+
+                constexpr int NS = C::tap_steps(t);
+                static_for<0, C::MPT>([&](auto m_c) {
+                    SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc);
                     constexpr int ml = decltype(m_c)::value;
                     constexpr int kc = ml / C::NCT, ct = ml % C::NCT;
-                    constexpr int f = (t * C::KC + kc) * C::NCT + ct;  // global MFMA index of the row
+                    constexpr int f = (t * C::KC + kc) * C::NCT + ct;  // MFMA index within the row
                     mfma_pinned<(f < C::NFA), (t == 0 && kc == 0)>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
-                    if constexpr (!C::OUT_F32) {
-                        // epilogue steps [f*NSTEP/NMFMA, (f+1)*NSTEP/NMFMA) of the previous row
-                        constexpr int s0 = f * C::NSTEP / C::NMFMA, s1 = (f + 1) * C::NSTEP / C::NMFMA;
-                        static_for<s0, s1>([&](auto s_c) { epi_step(s_c, IntC<PAR ^ 1>{}, y - 1, i > 0); });
-                        __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
-                    }
+                    // micro-steps [ml*NS/MPT, (ml+1)*NS/MPT) of this tap
+                    static_for<ml * NS / C::MPT, (ml + 1) * NS / C::MPT>([&](auto s_c) {
+                        SRHIP_CAPTURE(resv);
+                        constexpr int S = decltype(s_c)::value;
+                        if constexpr (t == 0) {
+                            if constexpr (S < C::NRES) resv[PAR][S] = buffer_load_b128_async(res_srd, vox[S], res_soff);
+                            else issue_piece(IntC<S - C::NRES>{}, i + C::LA);
+                        } else if constexpr (t & 1) {
+                            constexpr int W0 = (KG == 0 && C::HAS_RES) ? 1 : 0;
+                            if constexpr (S < W0) epi_res_wait(IntC<PAR ^ 1>{}, IntC<0>{});
+                            else epi_elem(IntC<KG>{}, IntC<S - W0>{}, IntC<PAR ^ 1>{});
+                        } else {
+                            if constexpr (S < 4) epi_elem(IntC<KG>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
+                            else epi_store(IntC<KG>{}, st_soff);
+                        }
+                    });
+                    if constexpr (NS > 0) __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
                 });
             });
 
@@ -478,7 +530,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous item's rows
 #pragma unroll 1
-        for (int r = 0; r < C::LA; ++r) issue_row(r);
+        for (int r = 0; r < C::LA; ++r) static_for<0, C::MAXP>([&](auto m_c) { issue_piece(m_c, r); });
 
 #pragma unroll 1
         for (int i = 0; i < nout; i += 2) {
@@ -488,20 +540,15 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 
         if constexpr (!C::OUT_F32) {
             // drain: second epilogue half of the last row
+            const unsigned st_soff = (unsigned)(y1 - 1) * out_pitch;
             auto tail = [&](auto ap_c) {
-                constexpr int AP = decltype(ap_c)::value;
-                static_for<0, C::NSTEP>([&](auto s_c) {
-                    constexpr int S = decltype(s_c)::value;
-                    if constexpr (S == 0) {
-                        if constexpr (C::HAS_RES) {
-                            if (my_pieces == C::MAXP) vm_wait<C::res_wait_tail(C::MAXP)>();
-                            else vm_wait<C::res_wait_tail(C::MAXP - 1)>();
-#pragma unroll
-                            for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));
-                        }
-                    } else {
-                        epi_step(s_c, ap_c, y1 - 1, true);
-                    }
+                epi_res_wait(ap_c, IntC<1>{});
+                static_for<0, C::NST>([&](auto k_c) {
+                    epi_read(k_c);
+                    lds_wait<0>();
+                    asm volatile("" : "+v"(e_lo), "+v"(e_hi));
+                    static_for<0, 8>([&](auto e_c) { epi_elem(k_c, e_c, ap_c); });
+                    epi_store(k_c, st_soff);
                 });
             };
             if ((nout - 1) & 1) tail(IntC<1>{});
@@ -642,10 +689,7 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     } else {
         SRHIP_REQUIRE(a->cout_stride % 8 == 0 && a->cout_stride >= a->cout && a->cout_stride <= 64, "conv3x3: bad cout_stride %d", a->cout_stride);
     }
-    int st = SRHIP_OK;
     ConvParams p;
-    p.zeros = (const char*)srhip_zero_page(&st);
-    if (st != SRHIP_OK) return st;
     p.src_a = (const char*)a->src_a;
     p.src_b = a->src_b ? (const char*)a->src_b : (const char*)a->src_a;
     p.wpack = (const bf16x8*)a->wpack;
@@ -653,13 +697,16 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     p.res = (const char*)a->res;
     p.dst = (char*)a->dst;
     p.n = a->n; p.h = a->h; p.w = a->w;
-    p.ca = a->ca; p.cb = a->cb; p.kc_a = a->ca / 16;
+    p.ca = a->ca; p.cb = a->cb;
     p.cout = a->cout; p.cout_stride = a->cout_stride;
     p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
     p.alpha = a->alpha;
-    p.dst_nchw_f32 = a->dst_nchw_f32;
     const int kc = (a->ca + a->cb) / 16;
     const int ct = (a->cout + 31) / 32;
+    // supported source splits: one tensor of 16/32/48/64 channels, or concat(32 channels, 64 channels)
+    if (a->cb != 0) SRHIP_REQUIRE(a->ca == 32 && a->cb == 64, "conv3x3: the only two-source form is concat(32 ch, 64 ch), got %d + %d", a->ca, a->cb);
+    else SRHIP_REQUIRE(a->ca <= 64, "conv3x3: a single source carries at most 64 channels (got %d)", a->ca);
+    SRHIP_REQUIRE(a->alpha > 0.0f, "conv3x3: alpha must be positive");
     hipStream_t s = (hipStream_t)stream;
 #define SRHIP_CONV_CASE(KC, CT, CSPLIT)                                                                 \
     if (kc == KC && ct == CT) {                                                                         \
