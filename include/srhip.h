@@ -37,6 +37,7 @@ typedef enum {
 
 typedef enum { SRHIP_ACT_NONE = 0, SRHIP_ACT_RELU = 1, SRHIP_ACT_LRELU = 2 } srhip_act;
 typedef enum { SRHIP_BILINEAR = 0, SRHIP_NEAREST = 1 } srhip_interp;
+typedef enum { SRHIP_RES_ADD = 0, SRHIP_RES_MASK = 1 } srhip_res_mode;
 
 SRHIP_API int srhip_version(void);
 SRHIP_API const char* srhip_last_error(void);
@@ -61,7 +62,12 @@ SRHIP_API int srhip_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, in
  * (SRResidualBlock: 0.2*f(x)+x), :111-115 (final_conv) and the 3x3 layers of
  * core/arch/RepRFN.py:158-161,252,315,322 (deploy form).
  *
- *   dst = alpha * act(conv(concat(src_a, src_b)) + bias) + res
+ *   dst = alpha * act(conv(concat(src_a, src_b)) + bias) + res          (res_mode ADD)
+ *   dst = res > 0 ? alpha * act(conv(...) + bias) : 0                   (res_mode MASK)
+ *
+ * The MASK form is the backward of conv -> ReLU chains: with transpose_flip
+ * weights the convolution yields dL/dx of the NEXT layer and `res` is the saved
+ * ReLU output of THIS layer, so the product is dL/d(pre-activation) in one pass.
  *
  * The channel concat of core/models/model.py:169-170 is folded into the K loop:
  * src_b may be NULL (cb = 0).
@@ -81,6 +87,7 @@ typedef struct {
     float slope;         /* LeakyReLU negative slope */
     float alpha;         /* scale applied after the activation (1.0 for none) */
     int dst_nchw_f32;    /* 1: write fp32 NCHW (network output / fp32-accumulate checks); no residual */
+    int res_mode;        /* srhip_res_mode: how `res` enters the epilogue */
 } srhip_conv3x3_args;
 
 /* Bytes of the packed-weight buffer for a (ca+cb) -> cout 3x3 layer. */
@@ -101,6 +108,20 @@ SRHIP_API int srhip_conv3x3_pack_weights(const float* w, void* wpack, int w_o, i
                                          int cb_pad, int transpose_flip, void* stream);
 
 SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* args, void* stream);
+
+/* Weight and bias gradient of the same layer (autograd backward of nn.Conv2d,
+ * core/models/model.py:12,26-28,112-114 via loss.backward() at core/trainer.py:160):
+ *   dw[co][ci_off+ci][ky][kx] (=|+=) sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]
+ *   db[co]                    (=|+=) sum_{n,y,x} dz[n,y,x,co]              (db may be NULL)
+ * x (N,H,W,ci_pad) and dz (N,H,W,co_pad) are NHWC bf16 with padded channel counts in
+ * {16,32,64}; dw is the fp32 OIHW gradient of a (co_real.., w_i, 3, 3) weight, of which this
+ * call fills input channels [ci_off, ci_off+ci_real) (a concat layer takes one call per source).
+ * workspace: srhip_conv3x3_wgrad_workspace_bytes() bytes of device memory, caller-owned.
+ * Deterministic (fixed-order two-stage reduction, no atomics). */
+SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void);
+SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace,
+                                  int n, int h, int w, int ci_pad, int ci_real, int ci_off, int w_i,
+                                  int co_pad, int co_real, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Generic direct convolution (any kernel size / stride / padding, NHWC bf16,
@@ -129,6 +150,21 @@ SRHIP_API int srhip_upsample_grid_bilinear_f32(const float* src, float* dst, int
 /* Its backward: dsrc (N,C,sh,sw) fp32 is ZEROED then accumulated (scatter-add). */
 SRHIP_API int srhip_upsample_grid_bilinear_bwd_f32(const float* ddst, float* dsrc, int n, int c,
                                                    int sh, int sw, int th, int tw, void* stream);
+
+/* Backward of the NHWC form as a gather (no atomics): ddst (N,th,tw,c) bf16 ->
+ * dsrc (N,sh,sw,c) bf16.  If relu_out is not NULL it is the saved (N,sh,sw,c) ReLU output that
+ * produced src, and dsrc is zeroed where relu_out <= 0 (ReLU backward fused). */
+SRHIP_API int srhip_upsample_grid_bilinear_bwd_nhwc(const void* ddst, const void* relu_out, void* dsrc,
+                                                    int n, int c, int sh, int sw, int th, int tw,
+                                                    void* stream);
+
+/* Element-wise helpers of the training graph on bf16 tensors of `count` elements (count % 8 == 0):
+ *   relu_mask: dst = y > 0 ? dy : 0     (backward of nn.ReLU, core/models/model.py:13)
+ *   add:       dst = a + b              (Residual, core/models/model.py:17-19, when the
+ *                                        un-added branch must be kept for the backward)
+ * dst may alias an input. */
+SRHIP_API int srhip_relu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, void* stream);
+SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t count, void* stream);
 
 /* Motion-vector backward warp, core/tools/math.py:10-17 (grid (x,y)-last as the
  * function evidently intends): frame (N,C,h,w), motion (N,2,h,w) in pixels,

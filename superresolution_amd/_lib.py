@@ -41,7 +41,7 @@ class Conv3x3Args(ctypes.Structure):
         ("ca", c_int), ("cb", c_int),
         ("cout", c_int), ("cout_stride", c_int),
         ("act", c_int), ("slope", c_float), ("alpha", c_float),
-        ("dst_nchw_f32", c_int),
+        ("dst_nchw_f32", c_int), ("res_mode", c_int),
     ]
 
 
@@ -54,11 +54,16 @@ _SIGNATURES = {
     "srhip_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p]),
     "srhip_conv3x3_fwd": (c_int, [ctypes.POINTER(Conv3x3Args), c_void_p]),
+    "srhip_conv3x3_wgrad_workspace_bytes": (c_size_t, []),
+    "srhip_conv3x3_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     "srhip_conv2d_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 +
                             [c_int, c_float, c_float, c_void_p]),
     "srhip_upsample_grid_bilinear_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_upsample_grid_bilinear_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_upsample_grid_bilinear_bwd_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_upsample_grid_bilinear_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_relu_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "srhip_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "srhip_backward_warp_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_backward_warp_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_backward_warp_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),

@@ -55,10 +55,11 @@ template <> struct SubLayout<3> { static constexpr int NSUB = 2; static constexp
 template <> struct SubLayout<4> { static constexpr int NSUB = 1; static constexpr int CS0 = 64, CS1 = 0; };
 template <> struct SubLayout<6> { static constexpr int NSUB = 2; static constexpr int CS0 = 32, CS1 = 64; };
 
-template <int KC_, int CT_TOTAL_, int CSPLIT_, bool OUT_F32_, bool HAS_RES_>
+template <int KC_, int CT_TOTAL_, int CSPLIT_, bool OUT_F32_, int RES_>
 struct Cfg {
     static constexpr bool OUT_F32 = OUT_F32_;   // epilogue writes fp32 NCHW instead of bf16 NHWC
-    static constexpr bool HAS_RES = HAS_RES_;   // a residual tensor is added in the epilogue (bf16 NHWC only)
+    static constexpr bool HAS_RES = RES_ != 0;  // the epilogue reads a second tensor `res` (bf16 NHWC only):
+    static constexpr bool RES_MASK = RES_ == 2; // 1: dst += res;  2: dst = res > 0 ? dst : 0 (ReLU backward)
     static constexpr int KC = KC_;              // 16-channel K planes
     static constexpr int CT_TOTAL = CT_TOTAL_;  // 32-wide output-channel tiles of the layer
     static constexpr int CSPLIT = CSPLIT_;      // waves that share a pixel group (split over cout tiles)
@@ -404,7 +405,9 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             float v = fmaxf(t, t * p.slope);  // act(t) = max(t, slope * t), slope in {1, 0, s}
             if constexpr (C::HAS_RES) {
                 const unsigned rr = resv[AP][k][e >> 1];
-                v += (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
+                const float rv = (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
+                if constexpr (C::RES_MASK) v = rv > 0.0f ? v : 0.0f;
+                else v += rv;
             }
             ev[e] = v;
         };
@@ -707,12 +710,14 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     if (a->cb != 0) SRHIP_REQUIRE(a->ca == 32 && a->cb == 64, "conv3x3: the only two-source form is concat(32 ch, 64 ch), got %d + %d", a->ca, a->cb);
     else SRHIP_REQUIRE(a->ca <= 64, "conv3x3: a single source carries at most 64 channels (got %d)", a->ca);
     SRHIP_REQUIRE(a->alpha > 0.0f, "conv3x3: alpha must be positive");
+    SRHIP_REQUIRE(a->res_mode == SRHIP_RES_ADD || a->res_mode == SRHIP_RES_MASK, "conv3x3: bad res_mode %d", a->res_mode);
     hipStream_t s = (hipStream_t)stream;
 #define SRHIP_CONV_CASE(KC, CT, CSPLIT)                                                                 \
     if (kc == KC && ct == CT) {                                                                         \
-        if (a->dst_nchw_f32) return launch_conv<Cfg<KC, CT, CSPLIT, true, false>>(p, s);                \
-        if (a->res != nullptr) return launch_conv<Cfg<KC, CT, CSPLIT, false, true>>(p, s);              \
-        return launch_conv<Cfg<KC, CT, CSPLIT, false, false>>(p, s);                                    \
+        if (a->dst_nchw_f32) return launch_conv<Cfg<KC, CT, CSPLIT, true, 0>>(p, s);                    \
+        if (a->res != nullptr && a->res_mode == SRHIP_RES_MASK) return launch_conv<Cfg<KC, CT, CSPLIT, false, 2>>(p, s); \
+        if (a->res != nullptr) return launch_conv<Cfg<KC, CT, CSPLIT, false, 1>>(p, s);                 \
+        return launch_conv<Cfg<KC, CT, CSPLIT, false, 0>>(p, s);                                        \
     }
     SRHIP_CONV_CASE(1, 1, 1)
     SRHIP_CONV_CASE(2, 1, 1)

@@ -1,0 +1,394 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution for gfx950 (autograd backward of
+// nn.Conv2d at core/models/model.py:12,26-28,112-114, reached through loss.backward() at
+// core/trainer.py:160):
+//
+//   dW[co][ci][ky][kx] = sum over (n, y, x) of dz[n][y][x][co] * xin[n][y+ky-1][x+kx-1][ci]
+//   db[co]             = sum over (n, y, x) of dz[n][y][x][co]
+//
+// A GEMM whose contraction runs over PIXELS: M = co, N = ci, K = pixels, one 32x32 output tile
+// per (co tile, ci tile, tap).  Both MFMA operands therefore need, per lane, runs of 8 consecutive
+// pixels of ONE channel, while HBM and LDS hold pixel-major NHWC rows; the transposing LDS read
+// ds_read_b64_tr_b16 delivers exactly that from the row-major image.
+//
+//   * A workgroup (4 waves, one per SIMD) walks vertical strips of 128 columns like the forward
+//     kernel.  Rows of xin (with a one-pixel halo) and of dz stream HBM -> LDS by buffer LDS-DMA
+//     into two rings; rows and columns outside the image fail the bounds check and land as zeros,
+//     which is the zero padding and also makes partial strips contribute nothing.
+//   * Wave w owns output tile (w % NT) for all 9 taps (9 accumulators of 16 registers) plus, for
+//     ci tile 0, the bias-gradient accumulator (dz times an all-ones operand).  Layers with fewer
+//     than 4 tiles split the strip's pixels between the waves that share a tile.
+//   * Accumulators persist over every work item of the workgroup; at the end each wave writes its
+//     partial tiles to the workspace and a second kernel sums them in a fixed order
+//     (deterministic, no atomics) into the fp32 OIHW gradient.
+//   * LDS image [pixel][channel]; for 64-channel rows the two 64-byte halves of a pixel are swapped
+//     on every second pixel pair (applied on the SOURCE side of the DMA) so that the transposing
+//     reads of 4 consecutive pixels x 32 channels touch every bank once.
+#include "srhip_common.h"
+
+namespace {
+
+struct WgradParams {
+    const char* x;
+    const char* dz;
+    float* partial;
+    int n, h, w;
+    int nstrips, nsegs, seg_h, total_items;
+};
+
+constexpr int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
+constexpr unsigned kOob = 0x80000000u;
+
+template <int CI_, int CO_>
+struct WCfg {
+    static constexpr int CI = CI_, CO = CO_;
+    static constexpr int NWAVES = 4, TW = 128;
+    static constexpr int CIT = CI >= 32 ? CI / 32 : 1;
+    static constexpr int COT = CO >= 32 ? CO / 32 : 1;
+    static constexpr int NT = CIT * COT;          // output tiles of the layer (1, 2 or 4)
+    static constexpr int KS = NWAVES / NT;        // waves sharing a tile split the strip's pixels
+    static constexpr int PXW = TW / KS;           // pixels per wave per row
+    static constexpr int NKS = PXW / 16;          // MFMA k-steps per wave per row and tap
+    static constexpr int XPB = CI * 2, ZPB = CO * 2;              // bytes per pixel
+    static constexpr int XPP = 1024 / XPB, ZPP = 1024 / ZPB;      // pixels per 1-KiB piece
+    static constexpr int XNP = round_up_i(TW + 2, XPP) / XPP;     // pieces per row
+    static constexpr int ZNP = TW / ZPP;
+    static constexpr int X_SLOT = XNP * 1024, Z_SLOT = ZNP * 1024;
+    static constexpr int XA = 4, ZA = 2;          // rows issued ahead
+    static constexpr int XRING = XA + 1, ZRING = ZA + 1;
+    static constexpr int Z_BASE = XRING * X_SLOT;
+    static constexpr int LDS_BYTES = Z_BASE + ZRING * Z_SLOT;
+    static constexpr int MAXPX = (XNP + NWAVES - 1) / NWAVES, MINPX = XNP / NWAVES;
+    static constexpr int MAXPZ = (ZNP + NWAVES - 1) / NWAVES, MINPZ = ZNP / NWAVES;
+    // Top of iteration i needs x row i+2 and dz row i, both issued in iteration i-2; the younger
+    // operations of this wave are at least one whole iteration.
+    static constexpr int TOP_WAIT = MINPX + MINPZ;
+    static_assert(XA >= 4 && ZA >= 2, "wait counts assume rows are issued two iterations ahead");
+};
+
+__device__ __forceinline__ void wg_lds_dma(__amdgpu_buffer_rsrc_t rsrc, __attribute__((address_space(3))) void* dst,
+                                           unsigned voffset, unsigned soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, (int)voffset, (int)soffset, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wg_vm_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wg_lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+}
+// Transposing LDS read (asm: the waits are counted by hand and the compiler must not order it
+// against the LDS-DMA writes, which it would do by draining the whole vector-memory queue).
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr)
+{
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+__device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi)
+{
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// byte offset of (pixel px, channel byte cb) inside a row slot with PB bytes per pixel
+template <int PB>
+__device__ __forceinline__ unsigned img_off(int px, int cb)
+{
+    if (PB == 128) return (unsigned)(px * 128 + (cb ^ (((px >> 1) & 1) << 6)));
+    return (unsigned)(px * PB + cb);
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const WgradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = wave % C::NT;
+    const int cot = tile / C::CIT, cit = tile % C::CIT;
+    const int part = wave / C::NT;       // which PXW-pixel part of the strip
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // ---- transposed-read lane roles: group g (16 lanes) reads the block of 4 pixels x 16 channels
+    // whose row q / channel quad p this lane addresses; lanes 0..31 hold k = 0..7, lanes 32..63 k = 8..15.
+    const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int chsel = 16 * (g & 1) + 4 * pq;
+    unsigned xaddr[3][2], zaddr[2];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2) {
+        const int pxl = part * C::PXW + 8 * (g >> 1) + 4 * j2 + q;
+        const int zcb = ((32 * cot + chsel) & (C::CO - 1)) * 2;
+        zaddr[j2] = lds_base + C::Z_BASE + img_off<C::ZPB>(pxl, zcb);
+        const int xcb = ((32 * cit + chsel) & (C::CI - 1)) * 2;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) xaddr[kx][j2] = lds_base + img_off<C::XPB>(pxl + kx, xcb);
+    }
+
+    const int H = p.h, W = p.w;
+    f32x16 acc[9];
+    f32x16 accb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3f80;
+
+    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+        const int strip = item % p.nstrips;
+        const int tseg = item / p.nstrips;
+        const int seg = tseg % p.nsegs;
+        const int n = tseg / p.nsegs;
+        const int x0 = strip * C::TW;
+        const int y0 = seg * p.seg_h;
+        const int y1 = min(y0 + p.seg_h, H);
+        const int nout = y1 - y0;
+
+        const unsigned img_x = (unsigned)(H * W) * (unsigned)C::XPB;
+        const unsigned img_z = (unsigned)(H * W) * (unsigned)C::ZPB;
+        const __amdgpu_buffer_rsrc_t rsrc_x =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long long)n * img_x), 0, (int)img_x, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_z =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.dz + (long long)n * img_z), 0, (int)img_z, 0x00020000);
+
+        // per-lane source offsets of this wave's DMA pieces (constant over the strip)
+        unsigned xoff[C::MAXPX], zoff[C::MAXPZ];
+#pragma unroll
+        for (int m = 0; m < C::MAXPX; ++m) {
+            const int L = (wave + m * C::NWAVES) * 64 + lane;  // 16-B chunk index inside the row slot
+            constexpr int CPP = C::XPB / 16;
+            const int px = L / CPP, s = L % CPP;
+            const int c = (C::XPB == 128) ? (s ^ (((px >> 1) & 1) << 2)) : s;
+            const int col = x0 - 1 + px;
+            const bool ok = col >= 0 && col < W && px < C::TW + 2;
+            xoff[m] = ok ? (unsigned)(col * C::XPB + c * 16) : kOob;
+        }
+#pragma unroll
+        for (int m = 0; m < C::MAXPZ; ++m) {
+            const int L = (wave + m * C::NWAVES) * 64 + lane;
+            constexpr int CPP = C::ZPB / 16;
+            const int px = L / CPP, s = L % CPP;
+            const int c = (C::ZPB == 128) ? (s ^ (((px >> 1) & 1) << 2)) : s;
+            const int col = x0 + px;
+            zoff[m] = col < W ? (unsigned)(col * C::ZPB + c * 16) : kOob;
+        }
+        // x row r <-> image row y0 - 1 + r (r = 0 .. nout+1); dz row r <-> image row y0 + r
+        auto issue_x = [&](const int r) {
+            const int y = y0 - 1 + r;
+            const unsigned soff = (y >= 0 && y < H && r < nout + 2) ? (unsigned)(y * W) * (unsigned)C::XPB : kOob;
+            char* slot = smem + (r % C::XRING) * C::X_SLOT;
+#pragma unroll
+            for (int m = 0; m < C::MAXPX; ++m) {
+                const int qq = wave + m * C::NWAVES;
+                if (qq < C::XNP)
+                    wg_lds_dma(rsrc_x, (__attribute__((address_space(3))) void*)(slot + qq * 1024), xoff[m], soff);
+            }
+        };
+        auto issue_z = [&](const int r) {
+            const unsigned soff = (r < nout) ? (unsigned)((y0 + r) * W) * (unsigned)C::ZPB : kOob;
+            char* slot = smem + C::Z_BASE + (r % C::ZRING) * C::Z_SLOT;
+#pragma unroll
+            for (int m = 0; m < C::MAXPZ; ++m) {
+                const int qq = wave + m * C::NWAVES;
+                if (qq < C::ZNP)
+                    wg_lds_dma(rsrc_z, (__attribute__((address_space(3))) void*)(slot + qq * 1024), zoff[m], soff);
+            }
+        };
+
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the previous item's rows
+#pragma unroll 1
+        for (int r = 0; r < C::XA; ++r) issue_x(r);
+#pragma unroll 1
+        for (int r = 0; r < C::ZA; ++r) issue_z(r);
+
+#pragma unroll 1
+        for (int i = 0; i < nout; ++i) {
+            if (i < 2) wg_vm_wait<0>();
+            else wg_vm_wait<C::TOP_WAIT>();
+            __builtin_amdgcn_s_barrier();
+            issue_x(i + C::XA);
+            issue_z(i + C::ZA);
+
+            const unsigned zs = (unsigned)((i % C::ZRING) * C::Z_SLOT);
+            unsigned xs[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) xs[ky] = (unsigned)(((i + ky) % C::XRING) * C::X_SLOT);
+
+            // dz fragments of this row (reused by all 9 taps)
+            bf16x4 alo[C::NKS], ahi[C::NKS];
+#pragma unroll
+            for (int s = 0; s < C::NKS; ++s) {
+                alo[s] = lds_read_tr<0>(zaddr[0] + zs + s * 16 * C::ZPB);
+                ahi[s] = lds_read_tr<0>(zaddr[1] + zs + s * 16 * C::ZPB);
+            }
+            // x fragments run one step ahead of the MFMAs
+            constexpr int NSTEP = 9 * C::NKS;
+            bf16x4 blo[2], bhi[2];
+            blo[0] = lds_read_tr<0>(xaddr[0][0] + xs[0]);
+            bhi[0] = lds_read_tr<0>(xaddr[0][1] + xs[0]);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                const int t = st / C::NKS, s = st % C::NKS;
+                const int cur = st & 1, nxt = cur ^ 1;
+                if (st + 1 < NSTEP) {
+                    const int tn = (st + 1) / C::NKS, sn = (st + 1) % C::NKS;
+                    blo[nxt] = lds_read_tr<0>(xaddr[tn % 3][0] + xs[tn / 3] + sn * 16 * C::XPB);
+                    bhi[nxt] = lds_read_tr<0>(xaddr[tn % 3][1] + xs[tn / 3] + sn * 16 * C::XPB);
+                    wg_lds_wait<2>();
+                } else {
+                    wg_lds_wait<0>();
+                }
+                if (st == 0) {
+#pragma unroll
+                    for (int k = 0; k < C::NKS; ++k) asm volatile("" : "+v"(alo[k]), "+v"(ahi[k]));
+                }
+                asm volatile("" : "+v"(blo[cur]), "+v"(bhi[cur]));  // consumers stay behind the wait
+                const bf16x8 a = join(alo[s], ahi[s]);
+                const bf16x8 b = join(blo[cur], bhi[cur]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                if (t == 4 && cit == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);
+            }
+        }
+        wg_vm_wait<0>();  // look-ahead rows past the item's end were issued as all-zero rows
+    }
+
+    // ---- partial tiles -> workspace [workgroup][wave][10][16 registers][64 lanes]
+    float* out = p.partial + ((size_t)(blockIdx.x * C::NWAVES + wave) * 10) * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = acc[t][r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(9 * 16 + r) * 64] = accb[r];
+}
+
+// Sums the partial tiles in a fixed order and scatters them into the fp32 OIHW gradient.
+// Accumulator register r of lane l holds row (r&3) + 8(r>>2) + 4(l>>5) (= co) and column l&31 (= ci).
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cit_n, int nt, float* __restrict__ dw,
+                                    int w_i, int ci_off, int ci_real, int co_real, int ci_pad32,
+                                    float* __restrict__ db, int accumulate)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nw = co_real * 9 * ci_pad32;
+    if (idx < nw) {
+        const int ci = idx % ci_pad32;
+        const int tap = (idx / ci_pad32) % 9;
+        const int co = idx / (ci_pad32 * 9);
+        if (ci >= ci_real) return;
+        const int tile = (co >> 5) * cit_n + (ci >> 5);
+        const int m = co & 31;
+        const int lane = (ci & 31) + 32 * ((m >> 2) & 1);
+        const int reg = (m & 3) + 4 * (m >> 3);
+        float s = 0.0f;
+        for (int wg = 0; wg < nwg; ++wg)
+            for (int wv = tile; wv < 4; wv += nt) s += partial[((size_t)(wg * 4 + wv) * 10 + tap) * 1024 + reg * 64 + lane];
+        float* o = dw + ((size_t)co * w_i + ci_off + ci) * 9 + tap;
+        *o = accumulate ? *o + s : s;
+    } else if (db != nullptr && idx < nw + co_real) {
+        const int co = idx - nw;
+        const int tile = (co >> 5) * cit_n;
+        const int m = co & 31;
+        const int lane = 32 * ((m >> 2) & 1);
+        const int reg = (m & 3) + 4 * (m >> 3);
+        float s = 0.0f;
+        for (int wg = 0; wg < nwg; ++wg)
+            for (int wv = tile; wv < 4; wv += nt) s += partial[((size_t)(wg * 4 + wv) * 10 + 9) * 1024 + reg * 64 + lane];
+        db[co] = accumulate ? db[co] + s : s;
+    }
+}
+
+template <class C>
+int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int ci_real, int co_real, int accumulate,
+                 hipStream_t stream)
+{
+    static bool configured = false;
+    if (!configured) {
+        if (C::LDS_BYTES > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            srhip_set_error("conv3x3_wgrad: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);
+            return SRHIP_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    const int slots = srhip_num_cus();
+    const int nstrips = srhip_div_up(p.w, C::TW);
+    int best_segs = 1;
+    double best_cost = 1e30;
+    for (int rounds = 1; rounds <= 16; ++rounds) {
+        int segs = (int)(((long long)rounds * slots) / ((long long)nstrips * p.n));
+        if (segs < 1) segs = 1;
+        if (segs > p.h) segs = p.h;
+        const int seg_h = srhip_div_up(p.h, segs);
+        segs = srhip_div_up(p.h, seg_h);
+        const long long items = (long long)segs * nstrips * p.n;
+        const int r = srhip_div_up(items, slots);
+        const double cost = (double)r * (seg_h + 2 + 6.0);
+        if (cost < best_cost) { best_cost = cost; best_segs = segs; }
+    }
+    p.seg_h = srhip_div_up(p.h, best_segs);
+    p.nsegs = srhip_div_up(p.h, p.seg_h);
+    p.nstrips = nstrips;
+    const long long total = (long long)p.nsegs * nstrips * p.n;
+    SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_wgrad: too many work items");
+    p.total_items = (int)total;
+    const int grid = (int)(total < slots ? total : slots);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<C>, dim3(grid), dim3(C::NWAVES * 64), C::LDS_BYTES, stream, p);
+    int rc = srhip_check_launch("conv3x3_wgrad_kernel");
+    if (rc != SRHIP_OK) return rc;
+    const int ci_pad32 = (ci_real + 31) / 32 * 32;
+    const int nthreads = co_real * 9 * ci_pad32 + co_real;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(srhip_div_up(nthreads, 128)), dim3(128), 0, stream, p.partial, grid,
+                       C::CIT, C::NT, dw, w_i, ci_off, ci_real, co_real, ci_pad32, db, accumulate);
+    return srhip_check_launch("wgrad_reduce_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void)
+{
+    return (size_t)srhip_num_cus() * 4 * 10 * 1024 * sizeof(float);
+}
+
+SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,
+                                  int w, int ci_pad, int ci_real, int ci_off, int w_i, int co_pad, int co_real,
+                                  int accumulate, void* stream)
+{
+    SRHIP_REQUIRE(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1, "conv3x3_wgrad: empty tensor");
+    SRHIP_REQUIRE(ci_real >= 1 && ci_real <= ci_pad && co_real >= 1 && co_real <= co_pad, "conv3x3_wgrad: real channels exceed padded");
+    SRHIP_REQUIRE(ci_off >= 0 && ci_off + ci_real <= w_i, "conv3x3_wgrad: input-channel window [%d,%d) outside the weight's %d", ci_off, ci_off + ci_real, w_i);
+    SRHIP_REQUIRE((long long)h * w * 64 * 2 < (1ll << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
+    WgradParams p;
+    p.x = (const char*)x;
+    p.dz = (const char*)dz;
+    p.partial = (float*)workspace;
+    p.n = n; p.h = h; p.w = w;
+    hipStream_t s = (hipStream_t)stream;
+#define SRHIP_WGRAD_CASE(CI, CO) \
+    if (ci_pad == CI && co_pad == CO) return launch_wgrad<WCfg<CI, CO>>(p, dw, db, w_i, ci_off, ci_real, co_real, accumulate, s);
+    SRHIP_WGRAD_CASE(64, 64)
+    SRHIP_WGRAD_CASE(32, 64)
+    SRHIP_WGRAD_CASE(16, 64)
+    SRHIP_WGRAD_CASE(64, 32)
+    SRHIP_WGRAD_CASE(32, 32)
+    SRHIP_WGRAD_CASE(16, 32)
+    SRHIP_WGRAD_CASE(64, 16)
+    SRHIP_WGRAD_CASE(32, 16)
+    SRHIP_WGRAD_CASE(16, 16)
+#undef SRHIP_WGRAD_CASE
+    srhip_set_error("conv3x3_wgrad: unsupported padded channels ci=%d co=%d (each must be 16, 32 or 64)", ci_pad, co_pad);
+    return SRHIP_ERR_INVALID;
+}
+
+}  // extern "C"

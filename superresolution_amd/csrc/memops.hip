@@ -137,6 +137,98 @@ __global__ void upsample_nhwc_kernel(const unsigned short* __restrict__ src, uns
     }
 }
 
+// Backward of upsample_nhwc_kernel as a gather: one thread = one SOURCE pixel x 8 channels.  Every
+// target pixel whose bilinear footprint touches the source pixel is found by re-evaluating the
+// forward's own fp32 index arithmetic over a conservative candidate range, so the weights are the
+// forward's weights bit for bit and no atomics are needed.
+__device__ __forceinline__ float tap_weight(CoordAxis a, int t, int ssize, int s)
+{
+    const float i = unnorm(coord_val(a, t), ssize, false);
+    const float f = floorf(i);
+    const int i0 = (int)f;
+    if (i0 == s) return (f + 1.0f) - i;
+    if (i0 + 1 == s) return i - f;
+    return 0.0f;
+}
+__global__ void upsample_bwd_nhwc_kernel(const unsigned short* __restrict__ ddst, const unsigned short* __restrict__ relu_out,
+                                         unsigned short* __restrict__ dsrc, int n, int c, int sh, int sw, int th,
+                                         int tw, CoordAxis ax, CoordAxis ay)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * sh * sw * cg;
+    const float rx = (float)tw / (float)sw, ry = (float)th / (float)sh;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int sx = (int)(p % sw); p /= sw;
+        const int sy = (int)(p % sh);
+        const int img = (int)(p / sh);
+        const int xlo = max(0, (int)floorf(((float)sx - 0.5f) * rx - 0.5f) - 1);
+        const int xhi = min(tw - 1, (int)ceilf(((float)sx + 1.5f) * rx - 0.5f) + 1);
+        const int ylo = max(0, (int)floorf(((float)sy - 0.5f) * ry - 0.5f) - 1);
+        const int yhi = min(th - 1, (int)ceilf(((float)sy + 1.5f) * ry - 0.5f) + 1);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int y = ylo; y <= yhi; ++y) {
+            const float wy = tap_weight(ay, y, sh, sy);
+            if (wy == 0.0f) continue;
+            const unsigned short* row = ddst + (((long long)img * th + y) * tw) * c + g * 8;
+            for (int x = xlo; x <= xhi; ++x) {
+                const float wx = tap_weight(ax, x, sw, sx);
+                if (wx == 0.0f) continue;
+                const float wgt = __fmul_rn(wx, wy);
+                const uint4 v = *(const uint4*)(row + (long long)x * c);
+                acc[0] += bf16_lo(v.x) * wgt; acc[1] += bf16_hi(v.x) * wgt;
+                acc[2] += bf16_lo(v.y) * wgt; acc[3] += bf16_hi(v.y) * wgt;
+                acc[4] += bf16_lo(v.z) * wgt; acc[5] += bf16_hi(v.z) * wgt;
+                acc[6] += bf16_lo(v.w) * wgt; acc[7] += bf16_hi(v.w) * wgt;
+            }
+        }
+        const long long o = (((long long)img * sh + sy) * sw + sx) * c + g * 8;
+        if (relu_out != nullptr) {
+            const uint4 m = *(const uint4*)(relu_out + o);
+            if (!(bf16_lo(m.x) > 0.0f)) acc[0] = 0.0f;
+            if (!(bf16_hi(m.x) > 0.0f)) acc[1] = 0.0f;
+            if (!(bf16_lo(m.y) > 0.0f)) acc[2] = 0.0f;
+            if (!(bf16_hi(m.y) > 0.0f)) acc[3] = 0.0f;
+            if (!(bf16_lo(m.z) > 0.0f)) acc[4] = 0.0f;
+            if (!(bf16_hi(m.z) > 0.0f)) acc[5] = 0.0f;
+            if (!(bf16_lo(m.w) > 0.0f)) acc[6] = 0.0f;
+            if (!(bf16_hi(m.w) > 0.0f)) acc[7] = 0.0f;
+        }
+        *(uint4*)(dsrc + o) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                                         pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+    }
+}
+
+// element-wise training helpers: 8 bf16 per thread
+__device__ __forceinline__ unsigned mask2(unsigned dy, unsigned y)
+{
+    const unsigned lo = (bf16_lo(y) > 0.0f) ? (dy & 0xffffu) : 0u;
+    const unsigned hi = (bf16_hi(y) > 0.0f) ? (dy & 0xffff0000u) : 0u;
+    return lo | hi;
+}
+__global__ void relu_mask_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y, uint4* __restrict__ dst,
+                                 long long nvec)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 a = dy[i], b = y[i];
+        dst[i] = make_uint4(mask2(a.x, b.x), mask2(a.y, b.y), mask2(a.z, b.z), mask2(a.w, b.w));
+    }
+}
+__device__ __forceinline__ unsigned add2(unsigned a, unsigned b)
+{
+    return pack_bf16x2(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));
+}
+__global__ void add_bf16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ dst,
+                                long long nvec)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 u = a[i], v = b[i];
+        dst[i] = make_uint4(add2(u.x, v.x), add2(u.y, v.y), add2(u.z, v.z), add2(u.w, v.w));
+    }
+}
+
 __global__ void warp_nhwc_kernel(const unsigned short* __restrict__ frame, const float* __restrict__ motion,
                                  unsigned short* __restrict__ dst, int n, int c, int h, int w, int mode, int align)
 {
@@ -563,6 +655,40 @@ SRHIP_API int srhip_make_coord(float* dst, int h, int w, void* stream)
     hipLaunchKernelGGL(make_coord_kernel, dim3(grid_for((long long)h * w, srhip_num_cus())), dim3(kThreads), 0,
                        (hipStream_t)stream, dst, h, w, coord_axis(w), coord_axis(h));
     return srhip_check_launch("make_coord");
+}
+
+SRHIP_API int srhip_upsample_grid_bilinear_bwd_nhwc(const void* ddst, const void* relu_out, void* dsrc, int n, int c,
+                                                    int sh, int sw, int th, int tw, void* stream)
+{
+    SRHIP_REQUIRE(ddst && dsrc, "upsample_grid_bilinear_bwd_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && sh >= 1 && sw >= 1 && th >= 1 && tw >= 1, "upsample_grid_bilinear_bwd_nhwc: bad shape (c must be a multiple of 8)");
+    const long long work = (long long)n * sh * sw * (c / 8);
+    hipLaunchKernelGGL(upsample_bwd_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const unsigned short*)ddst, (const unsigned short*)relu_out, (unsigned short*)dsrc, n, c, sh, sw, th, tw,
+                       coord_axis(tw), coord_axis(th));
+    return srhip_check_launch("upsample_bwd_nhwc");
+}
+
+SRHIP_API int srhip_relu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, void* stream)
+{
+    SRHIP_REQUIRE(dy && y && dst, "relu_mask_bf16: null pointer");
+    SRHIP_REQUIRE(count % 8 == 0, "relu_mask_bf16: count must be a multiple of 8");
+    if (count == 0) return SRHIP_OK;
+    const long long nvec = (long long)(count / 8);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)dy, (const uint4*)y, (uint4*)dst, nvec);
+    return srhip_check_launch("relu_mask_bf16");
+}
+
+SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t count, void* stream)
+{
+    SRHIP_REQUIRE(a && b && dst, "add_bf16: null pointer");
+    SRHIP_REQUIRE(count % 8 == 0, "add_bf16: count must be a multiple of 8");
+    if (count == 0) return SRHIP_OK;
+    const long long nvec = (long long)(count / 8);
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)a, (const uint4*)b, (uint4*)dst, nvec);
+    return srhip_check_launch("add_bf16");
 }
 
 SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t pixels, int ca, int cb, void* stream)

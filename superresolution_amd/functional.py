@@ -11,6 +11,7 @@ import torch
 from ._lib import Conv3x3Args, check, lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+RES_ADD, RES_MASK = 0, 1
 _MODES = {"bilinear": 0, "nearest": 1}
 
 
@@ -77,8 +78,10 @@ def conv3x3_pack_weights(weight: torch.Tensor, cin_a_real: int, ca_pad: int, cin
 def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
             src_b: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
             slope: float = 0.0, alpha: float = 1.0, out_nchw_f32: bool = False,
-            cout_stride: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dst = alpha * act(conv3x3(concat(src_a, src_b)) + bias) + res   (NHWC bf16 activations)."""
+            cout_stride: Optional[int] = None, out: Optional[torch.Tensor] = None,
+            res_mode: int = RES_ADD) -> torch.Tensor:
+    """dst = alpha * act(conv3x3(concat(src_a, src_b)) + bias) + res   (NHWC bf16 activations);
+    with ``res_mode=RES_MASK``: dst = res > 0 ? alpha * act(...) : 0."""
     src_a = _req(src_a, torch.bfloat16, "src_a")
     n, h, w, ca = src_a.shape
     cb = 0
@@ -103,8 +106,76 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
                 raise ValueError("conv3x3: residual shape must equal the output shape")
     a = Conv3x3Args(src_a=src_a.data_ptr(), src_b=_ptr(src_b), wpack=wpack.data_ptr(), bias=_ptr(bias),
                     res=_ptr(res), dst=out.data_ptr(), n=n, h=h, w=w, ca=ca, cb=cb, cout=cout,
-                    cout_stride=cout_stride, act=act, slope=slope, alpha=alpha, dst_nchw_f32=int(out_nchw_f32))
+                    cout_stride=cout_stride, act=act, slope=slope, alpha=alpha, dst_nchw_f32=int(out_nchw_f32),
+                    res_mode=res_mode)
     check(lib.srhip_conv3x3_fwd(a, _stream()))
+    return out
+
+
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(device) -> torch.Tensor:
+    ws = _wgrad_ws.get(device)
+    if ws is None:
+        with torch.cuda.device(device):
+            ws = torch.empty((lib.srhip_conv3x3_wgrad_workspace_bytes(),), dtype=torch.uint8, device=device)
+        _wgrad_ws[device] = ws
+    return ws
+
+
+def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], ci_real: int,
+                  co_real: int, ci_off: int = 0, accumulate: bool = False) -> None:
+    """dw[:, ci_off:ci_off+ci_real] (=|+=) weight gradient of a 3x3 layer from its input x (N,H,W,ci_pad) and the
+    gradient dz (N,H,W,co_pad) of its pre-activation output; db (=|+=) bias gradient (or None)."""
+    x = _req(x, torch.bfloat16, "x")
+    dz = _req(dz, torch.bfloat16, "dz")
+    if x.shape[:3] != dz.shape[:3]:
+        raise ValueError("conv3x3_wgrad: x and dz disagree on (N,H,W)")
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.dim() != 4 or tuple(dw.shape[2:]) != (3, 3):
+        raise ValueError("conv3x3_wgrad: dw must be a contiguous fp32 (O,I,3,3) tensor")
+    if dw.shape[0] < co_real:
+        raise ValueError("conv3x3_wgrad: dw has fewer output channels than co_real")
+    if db is not None and (db.dtype != torch.float32 or db.numel() < co_real):
+        raise ValueError("conv3x3_wgrad: db must be fp32[co_real]")
+    n, h, w, ci_pad = x.shape
+    check(lib.srhip_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _ptr(db), _wgrad_workspace(x.device).data_ptr(),
+                                  n, h, w, ci_pad, ci_real, ci_off, dw.shape[1], dz.shape[3], co_real, int(accumulate),
+                                  _stream()))
+
+
+def relu_mask(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy where y > 0 else 0 (bf16)."""
+    dy = _req(dy, torch.bfloat16, "dy")
+    y = _req(y, torch.bfloat16, "y")
+    if dy.shape != y.shape:
+        raise ValueError("relu_mask: shapes differ")
+    out = torch.empty_like(dy) if out is None else out
+    check(lib.srhip_relu_mask_bf16(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), _stream()))
+    return out
+
+
+def add_bf16(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    a = _req(a, torch.bfloat16, "a")
+    b = _req(b, torch.bfloat16, "b")
+    if a.shape != b.shape:
+        raise ValueError("add_bf16: shapes differ")
+    out = torch.empty_like(a) if out is None else out
+    check(lib.srhip_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()))
+    return out
+
+
+def upsample_grid_bilinear_bwd_nhwc(dy: torch.Tensor, sh: int, sw: int, relu_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Backward of upsample_grid_bilinear_nhwc: dy (N,th,tw,C) bf16 -> (N,sh,sw,C) bf16, optionally masked by the
+    ReLU output that produced the source."""
+    dy = _req(dy, torch.bfloat16, "dy")
+    n, th, tw, c = dy.shape
+    if relu_out is not None:
+        relu_out = _req(relu_out, torch.bfloat16, "relu_out")
+        if tuple(relu_out.shape) != (n, sh, sw, c):
+            raise ValueError("upsample_grid_bilinear_bwd_nhwc: relu_out shape mismatch")
+    out = torch.empty((n, sh, sw, c), dtype=torch.bfloat16, device=dy.device)
+    check(lib.srhip_upsample_grid_bilinear_bwd_nhwc(dy.data_ptr(), _ptr(relu_out), out.data_ptr(), n, c, sh, sw, th, tw, _stream()))
     return out
 
 

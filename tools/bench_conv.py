@@ -50,3 +50,23 @@ if __name__ == "__main__":
     case("16->32 relu LR", 16, 0, 32, h=540, w=960)
     case("32->32 relu LR", 32, 0, 32, h=540, w=960)
     case("64->64 relu 16x1024^2", 64, 0, 64, h=1024, w=1024, n=16)
+
+
+def wgrad_case(name, ci, co, h=1024, w=1024, n=16):
+    x = (torch.rand(n, h, w, ci, device=dev) - 0.5).to(torch.bfloat16)
+    dz = (torch.rand(n, h, w, co, device=dev) - 0.5).to(torch.bfloat16)
+    dw = torch.empty(co, ci, 3, 3, device=dev)
+    db = torch.empty(co, device=dev)
+    fn = lambda: F_.conv3x3_wgrad(x, dz, dw, db, ci, co)
+    med, best = timeit(fn)
+    flop = 2.0 * n * h * w * co * ci * 9
+    byts = n * h * w * (ci + co) * 2
+    print(f"wgrad {name:22s} median {med:7.3f} ms  best {best:7.3f} ms  {flop / med / 1e9:8.1f} TFLOP/s  {byts / med / 1e6:7.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "quick"):
+    wgrad_case("64x64 16x1024^2", 64, 64)
+    wgrad_case("32x64 16x1024^2", 32, 64)
+    wgrad_case("16x64 16x1024^2", 16, 64)
+    wgrad_case("64x16 16x1024^2", 64, 16)
+    wgrad_case("32x32 16x256^2", 32, 32, h=256, w=256)
