@@ -111,8 +111,10 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* args, void* stream);
 
 /* Weight and bias gradient of the same layer (autograd backward of nn.Conv2d,
  * core/models/model.py:12,26-28,112-114 via loss.backward() at core/trainer.py:160):
- *   dw[co][ci_off+ci][ky][kx] (=|+=) sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]
- *   db[co]                    (=|+=) sum_{n,y,x} dz[n,y,x,co]              (db may be NULL)
+ *   dw[co][ci_off+ci][ky][kx] (=|+=) scale * sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]
+ *   db[co]                    (=|+=) scale * sum_{n,y,x} dz[n,y,x,co]      (db may be NULL)
+ * (`scale` carries a constant factor of the layer's output, e.g. the 0.2 of
+ * core/models/model.py:33, so that dz need not be rescaled in memory.)
  * x (N,H,W,ci_pad) and dz (N,H,W,co_pad) are NHWC bf16 with padded channel counts in
  * {16,32,64}; dw is the fp32 OIHW gradient of a (co_real.., w_i, 3, 3) weight, of which this
  * call fills input channels [ci_off, ci_off+ci_real) (a concat layer takes one call per source).
@@ -121,7 +123,7 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* args, void* stream);
 SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void);
 SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace,
                                   int n, int h, int w, int ci_pad, int ci_real, int ci_off, int w_i,
-                                  int co_pad, int co_real, int accumulate, void* stream);
+                                  int co_pad, int co_real, int accumulate, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Generic direct convolution (any kernel size / stride / padding, NHWC bf16,

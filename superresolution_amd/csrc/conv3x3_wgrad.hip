@@ -272,42 +272,60 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
 
 // Sums the partial tiles in a fixed order and scatters them into the fp32 OIHW gradient.
 // Accumulator register r of lane l holds row (r&3) + 8(r>>2) + 4(l>>5) (= co) and column l&31 (= ci).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cit_n, int nt, float* __restrict__ dw,
-                                    int w_i, int ci_off, int ci_real, int co_real, int ci_pad32,
-                                    float* __restrict__ db, int accumulate)
+// A block of 256 threads owns 32 consecutive outputs (one 128-byte line of every partial tile);
+// 8 thread groups each sum every 8th partial, then the 8 sums are added in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cit_n, int nt,
+                                                           float* __restrict__ dw, int w_i, int ci_off, int ci_real,
+                                                           int co_real, int ci_pad32, float* __restrict__ db,
+                                                           int accumulate, float scale)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + o;
     const int nw = co_real * 9 * ci_pad32;
+    // decode the output this thread column reduces: weight element, bias element, or nothing
+    int tile = 0, elem = -1;   // elem: float offset inside a wave's partial block
+    float* dst = nullptr;
     if (idx < nw) {
         const int ci = idx % ci_pad32;
         const int tap = (idx / ci_pad32) % 9;
         const int co = idx / (ci_pad32 * 9);
-        if (ci >= ci_real) return;
-        const int tile = (co >> 5) * cit_n + (ci >> 5);
-        const int m = co & 31;
-        const int lane = (ci & 31) + 32 * ((m >> 2) & 1);
-        const int reg = (m & 3) + 4 * (m >> 3);
-        float s = 0.0f;
-        for (int wg = 0; wg < nwg; ++wg)
-            for (int wv = tile; wv < 4; wv += nt) s += partial[((size_t)(wg * 4 + wv) * 10 + tap) * 1024 + reg * 64 + lane];
-        float* o = dw + ((size_t)co * w_i + ci_off + ci) * 9 + tap;
-        *o = accumulate ? *o + s : s;
+        if (ci < ci_real) {
+            const int m = co & 31;
+            tile = (co >> 5) * cit_n + (ci >> 5);
+            elem = tap * 1024 + ((m & 3) + 4 * (m >> 3)) * 64 + (ci & 31) + 32 * ((m >> 2) & 1);
+            dst = dw + ((size_t)co * w_i + ci_off + ci) * 9 + tap;
+        }
     } else if (db != nullptr && idx < nw + co_real) {
         const int co = idx - nw;
-        const int tile = (co >> 5) * cit_n;
         const int m = co & 31;
-        const int lane = 32 * ((m >> 2) & 1);
-        const int reg = (m & 3) + 4 * (m >> 3);
-        float s = 0.0f;
-        for (int wg = 0; wg < nwg; ++wg)
-            for (int wv = tile; wv < 4; wv += nt) s += partial[((size_t)(wg * 4 + wv) * 10 + 9) * 1024 + reg * 64 + lane];
-        db[co] = accumulate ? db[co] + s : s;
+        tile = (co >> 5) * cit_n;
+        elem = 9 * 1024 + ((m & 3) + 4 * (m >> 3)) * 64 + 32 * ((m >> 2) & 1);
+        dst = db + co;
+    }
+    const int ks = 4 / nt;
+    const int total = nwg * ks;
+    float s = 0.0f;
+    if (elem >= 0) {
+        for (int k = part; k < total; k += 8) {
+            const int wg = k / ks, wv = tile + (k % ks) * nt;
+            s += partial[(size_t)(wg * 4 + wv) * 10240 + elem];
+        }
+    }
+    red[part][o] = s;
+    __syncthreads();
+    if (part == 0 && elem >= 0) {
+        float t = red[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][o];
+        t *= scale;
+        *dst = accumulate ? *dst + t : t;
     }
 }
 
 template <class C>
 int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int ci_real, int co_real, int accumulate,
-                 hipStream_t stream)
+                 float scale, hipStream_t stream)
 {
     static bool configured = false;
     if (!configured) {
@@ -346,8 +364,8 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
     if (rc != SRHIP_OK) return rc;
     const int ci_pad32 = (ci_real + 31) / 32 * 32;
     const int nthreads = co_real * 9 * ci_pad32 + co_real;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(srhip_div_up(nthreads, 128)), dim3(128), 0, stream, p.partial, grid,
-                       C::CIT, C::NT, dw, w_i, ci_off, ci_real, co_real, ci_pad32, db, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(srhip_div_up(nthreads, 32)), dim3(256), 0, stream, p.partial, grid,
+                       C::CIT, C::NT, dw, w_i, ci_off, ci_real, co_real, ci_pad32, db, accumulate, scale);
     return srhip_check_launch("wgrad_reduce_kernel");
 }
 
@@ -362,7 +380,7 @@ SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void)
 
 SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,
                                   int w, int ci_pad, int ci_real, int ci_off, int w_i, int co_pad, int co_real,
-                                  int accumulate, void* stream)
+                                  int accumulate, float scale, void* stream)
 {
     SRHIP_REQUIRE(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
     SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1, "conv3x3_wgrad: empty tensor");
@@ -376,7 +394,7 @@ SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, floa
     p.n = n; p.h = h; p.w = w;
     hipStream_t s = (hipStream_t)stream;
 #define SRHIP_WGRAD_CASE(CI, CO) \
-    if (ci_pad == CI && co_pad == CO) return launch_wgrad<WCfg<CI, CO>>(p, dw, db, w_i, ci_off, ci_real, co_real, accumulate, s);
+    if (ci_pad == CI && co_pad == CO) return launch_wgrad<WCfg<CI, CO>>(p, dw, db, w_i, ci_off, ci_real, co_real, accumulate, scale, s);
     SRHIP_WGRAD_CASE(64, 64)
     SRHIP_WGRAD_CASE(32, 64)
     SRHIP_WGRAD_CASE(16, 64)

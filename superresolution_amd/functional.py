@@ -125,7 +125,7 @@ def _wgrad_workspace(device) -> torch.Tensor:
 
 
 def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], ci_real: int,
-                  co_real: int, ci_off: int = 0, accumulate: bool = False) -> None:
+                  co_real: int, ci_off: int = 0, accumulate: bool = False, scale: float = 1.0) -> None:
     """dw[:, ci_off:ci_off+ci_real] (=|+=) weight gradient of a 3x3 layer from its input x (N,H,W,ci_pad) and the
     gradient dz (N,H,W,co_pad) of its pre-activation output; db (=|+=) bias gradient (or None)."""
     x = _req(x, torch.bfloat16, "x")
@@ -141,7 +141,7 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw: torch.Tensor, db: Optio
     n, h, w, ci_pad = x.shape
     check(lib.srhip_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _ptr(db), _wgrad_workspace(x.device).data_ptr(),
                                   n, h, w, ci_pad, ci_real, ci_off, dw.shape[1], dz.shape[3], co_real, int(accumulate),
-                                  _stream()))
+                                  scale, _stream()))
 
 
 def relu_mask(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -90,14 +90,30 @@ class SuperSampler(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     # ------------------------------------------------------------------ packed-weight cache
+    def _cached_pack(self, key: str, w: Tensor, build) -> Tensor:
+        tag = (w._version, w.data_ptr(), w.device)
+        hit = self._packs.get(key)
+        if hit is None or hit[0] != tag:
+            hit = (tag, build())
+            self._packs[key] = hit
+        return hit[1]
+
     def _pack(self, name: str, conv: nn.Conv2d, cin_a: int, ca_pad: int, cin_b: int = 0, cb_pad: int = 0) -> Tensor:
         w = conv.weight
-        tag = (w._version, w.data_ptr(), w.device)
-        hit = self._packs.get(name)
-        if hit is None or hit[0] != tag:
-            hit = (tag, F_.conv3x3_pack_weights(w.detach(), cin_a, ca_pad, cin_b, cb_pad))
-            self._packs[name] = hit
-        return hit[1]
+        return self._cached_pack(name, w, lambda: F_.conv3x3_pack_weights(w.detach(), cin_a, ca_pad, cin_b, cb_pad))
+
+    def _dgrad(self, name: str, conv: nn.Conv2d, dz: Tensor, lo: int = 0, n: int = None, mask: Tensor = None,
+               res: Tensor = None, alpha: float = 1.0) -> Tensor:
+        """Gradient w.r.t. input channels [lo, lo+n) of ``conv`` from dz, the gradient of its pre-activation
+        output: alpha * conv_transpose(dz), then either masked by a saved ReLU output (``mask``) or added to
+        ``res``.  Runs the forward kernel on transposed, flipped weights."""
+        w = conv.weight
+        n = conv.in_channels - lo if n is None else n
+        wp = self._cached_pack(f"{name}^T{lo}", w, lambda: F_.conv3x3_pack_weights(
+            w.detach(), conv.out_channels, dz.shape[-1], cout=n, cout_off=lo, transpose_flip=True))
+        second = mask if mask is not None else res
+        return F_.conv3x3(dz, wp, None, n, res=second, act=F_.ACT_NONE, alpha=alpha,
+                          res_mode=F_.RES_MASK if mask is not None else F_.RES_ADD)
 
     def _conv(self, name: str, conv: nn.Conv2d, x: Tensor, cin_a: int, xb: Tensor = None, cin_b: int = 0,
               res: Tensor = None, act: int = F_.ACT_RELU, alpha: float = 1.0, out_nchw_f32: bool = False) -> Tensor:

@@ -1,0 +1,145 @@
+"""Training path of the default network: forward with saved activations and a hand-written
+backward, both on libsrhip.so, exposed to torch as one ``autograd.Function``.
+
+What the reference does with ``loss.backward()`` (core/trainer.py:160) through ATen's per-operator
+autograd is done here layer by layer on NHWC bf16 tensors:
+
+  * data gradient of a 3x3 layer = the forward MFMA kernel on ``transpose_flip`` weights, with the
+    ReLU backward of the *producing* layer fused as a mask epilogue and the residual fan-in fused
+    as an add epilogue;
+  * weight and bias gradients = the MFMA weight-gradient kernel (fp32 accumulate, fp32 OIHW out);
+  * the 0.2 of ``SRResidualBlock`` (core/models/model.py:33) travels as ``alpha`` / ``scale``;
+  * the up-sampling backward is a gather with the frame extractor's last ReLU fused.
+
+Master weights, gradients handed to the optimiser and the network output are fp32, activations and
+activation gradients bf16 (fp32 accumulation inside every kernel).
+"""
+from typing import List
+
+import torch
+from torch import Tensor
+
+from . import functional as F_
+
+
+def _wgrad(x: Tensor, dz: Tensor, conv, grads: dict, ci_real: int, ci_off: int = 0, scale: float = 1.0,
+           with_bias: bool = True) -> None:
+    dw = grads.get(id(conv.weight))
+    if dw is None:
+        dw = torch.empty_like(conv.weight, memory_format=torch.contiguous_format)
+        grads[id(conv.weight)] = dw
+    db = None
+    if with_bias and conv.bias is not None:
+        db = torch.empty_like(conv.bias)
+        grads[id(conv.bias)] = db
+    F_.conv3x3_wgrad(x, dz, dw, db, ci_real, conv.out_channels, ci_off=ci_off, scale=scale)
+
+
+class _SuperSamplerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, lr: Tensor, hb: Tensor, *params: Tensor) -> Tensor:
+        m = model
+        th, tw = hb.shape[-2:]
+        fc, bc, fr, bf, sr = m.frame_channels, m.buffer_channels, m.FR_CH, m.BF_CH, m.SR_CH
+        sv = {}
+        # frame extractor @ LR (core/models/model.py:50-58,161)
+        f = [F_.nchw_f32_to_nhwc_bf16(lr.float())]
+        cin = fc
+        for i, blk in enumerate(m.frame_extractor.blks):
+            f.append(m._conv(f"fe{i}", blk[0], f[-1], cin))
+            cin = fr
+        up = F_.upsample_grid_bilinear_nhwc(f[-1], th, tw)
+        # G-buffer extractor @ HR (model.py:61-79,167); the residual sum is kept apart from its
+        # ReLU branch because the backward needs the branch's own sign pattern
+        blks = m.gbuffers_extractor.blks
+        gb = []
+        prev, cin = F_.nchw_f32_to_nhwc_bf16(hb.float()), bc
+        for i in range(0, len(blks), 2):
+            x = m._conv(f"ge{i}", blks[i][0], prev, cin)
+            t1 = m._conv(f"ge{i + 1}a", blks[i + 1][0][0], x, bf)
+            t2 = m._conv(f"ge{i + 1}b", blks[i + 1][1][0], t1, bf)
+            gb.append((prev, x, t1, t2))
+            prev, cin = F_.add_bf16(x, t2), bf
+        g = prev
+        # main trunk (model.py:82-95,169)
+        xs = [m._conv("main_in", m.main.conv_in[0], up, fr, xb=g, cin_b=bf)]
+        ts = []
+        for i, blk in enumerate(m.main.conv_main):
+            ts.append(m._conv(f"m{i}a", blk.blks[0], xs[-1], sr))
+            xs.append(m._conv(f"m{i}b", blk.blks[2], ts[-1], sr, res=xs[-1], act=F_.ACT_NONE, alpha=0.2))
+        a = m._conv("after", m.after_main[0], up, fr, xb=xs[-1], cin_b=sr)
+        c0 = m._conv("fin0", m.final_conv[0], a, sr)
+        out = m._conv("fin2", m.final_conv[2], c0, sr, act=F_.ACT_NONE, out_nchw_f32=True)
+        sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]))
+        ctx.model, ctx.sv = m, sv
+        return out
+
+    @staticmethod
+    def backward(ctx, dsr: Tensor):
+        m, sv = ctx.model, ctx.sv
+        fc, bc, fr, bf, sr = m.frame_channels, m.buffer_channels, m.FR_CH, m.BF_CH, m.SR_CH
+        grads = {}
+        dgrad = m._dgrad
+        f, up, gb, g, xs, ts, a, c0 = sv["f"], sv["up"], sv["gb"], sv["g"], sv["xs"], sv["ts"], sv["a"], sv["c0"]
+
+        # final_conv (model.py:111-115,172)
+        fin0, fin2 = m.final_conv[0], m.final_conv[2]
+        dz = F_.nchw_f32_to_nhwc_bf16(dsr.float().contiguous())
+        _wgrad(c0, dz, fin2, grads, sr)
+        d = dgrad("fin2", fin2, dz, mask=c0)
+        _wgrad(a, d, fin0, grads, sr)
+        d = dgrad("fin0", fin0, d, mask=a)
+        # after_main on concat(up, x6) (model.py:170)
+        aft = m.after_main[0]
+        _wgrad(up, d, aft, grads, fr, ci_off=0)
+        _wgrad(xs[-1], d, aft, grads, sr, ci_off=fr, with_bias=False)
+        dup = dgrad("after", aft, d, lo=0, n=fr)
+        dx = dgrad("after", aft, d, lo=fr, n=sr)
+        del d
+        # SRResidualBlocks, last to first: x_{i+1} = x_i + 0.2 * conv_b(relu(conv_a(x_i)))
+        for i in reversed(range(len(m.main.conv_main))):
+            blk = m.main.conv_main[i].blks
+            _wgrad(ts[i], dx, blk[2], grads, sr, scale=0.2)
+            g2 = dgrad(f"m{i}b", blk[2], dx, alpha=0.2, mask=ts[i])
+            _wgrad(xs[i], g2, blk[0], grads, sr)
+            dx = dgrad(f"m{i}a", blk[0], g2, res=dx)
+        # conv_in on concat(up, g) (model.py:85,169)
+        cin_ = m.main.conv_in[0]
+        d = F_.relu_mask(dx, xs[0], out=dx)
+        _wgrad(up, d, cin_, grads, fr, ci_off=0)
+        _wgrad(g, d, cin_, grads, bf, ci_off=fr, with_bias=False)
+        dup = dgrad("main_in", cin_, d, lo=0, n=fr, res=dup)
+        dg = dgrad("main_in", cin_, d, lo=fr, n=bf)
+        del d, dx
+        # G-buffer extractor, last block first: out = x + relu(conv_b(relu(conv_a(x)))), x = relu(conv(prev))
+        blks = m.gbuffers_extractor.blks
+        for b in reversed(range(len(gb))):
+            prev, x, t1, t2 = gb[b]
+            conv0, conva, convb = blks[2 * b][0], blks[2 * b + 1][0][0], blks[2 * b + 1][1][0]
+            dt2 = F_.relu_mask(dg, t2)
+            _wgrad(t1, dt2, convb, grads, bf)
+            dt1 = dgrad(f"ge{2 * b + 1}b", convb, dt2, mask=t1)
+            _wgrad(x, dt1, conva, grads, bf)
+            dxb = dgrad(f"ge{2 * b + 1}a", conva, dt1, res=dg)
+            dzb = F_.relu_mask(dxb, x, out=dxb)
+            _wgrad(prev, dzb, conv0, grads, bc if b == 0 else bf)
+            if b > 0:
+                dg = dgrad(f"ge{2 * b}", conv0, dzb)
+        # frame extractor @ LR through the up-sampling (model.py:161-162)
+        sh, sw = sv["lr_hw"]
+        fe = m.frame_extractor.blks
+        d = F_.upsample_grid_bilinear_bwd_nhwc(dup, sh, sw, relu_out=f[3])
+        _wgrad(f[2], d, fe[2][0], grads, fr)
+        d = dgrad("fe2", fe[2][0], d, mask=f[2])
+        _wgrad(f[1], d, fe[1][0], grads, fr)
+        d = dgrad("fe1", fe[1][0], d, mask=f[1])
+        _wgrad(f[0], d, fe[0][0], grads, fc)
+        ctx.sv = None
+        return (None, None, None) + tuple(grads.get(id(p)) for p in m.parameters())
+
+
+def supersampler_forward_train(model, lr: Tensor, hb: Tensor) -> Tensor:
+    """Differentiable forward: (B,3,sh,sw), (B,10,th,tw) fp32 -> (B,3,th,tw) fp32 with a grad_fn that
+    fills ``.grad`` of every parameter of ``model``."""
+    params: List[Tensor] = list(model.parameters())
+    return _SuperSamplerFn.apply(model, lr, hb, *params)

@@ -1,0 +1,95 @@
+"""Data-parallel plumbing on CPU: two gloo ranks (no GPU needed)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters, shard_range
+        torch.manual_seed(100 + rank)  # replicas start different on purpose
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 3, padding=1))
+        broadcast_parameters(net, src=0)
+        w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        red = FlatGradAllReducer(net.parameters())
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+        # global batch of 4 samples, sharded 2 per rank
+        g = torch.Generator().manual_seed(7)
+        x_all, y_all = torch.randn(4, 3, 8, 8, generator=g), torch.randn(4, 2, 8, 8, generator=g)
+        idx = list(shard_range(4, rank, world))
+        for _ in range(2):
+            red.zero_grad()
+            loss = torch.nn.functional.mse_loss(net(x_all[idx]), y_all[idx])
+            loss.backward()
+            red.check_views()
+            red.all_reduce()
+            opt.step()
+        w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        q.put((rank, w0.numpy().copy(), w.numpy().copy(), idx))  # plain arrays: no shared-memory handles
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_process_reference(w0):
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 3, padding=1))
+    off = 0
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(w0[off:off + p.numel()].view_as(p))
+            off += p.numel()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(7)
+    x_all, y_all = torch.randn(4, 3, 8, 8, generator=g), torch.randn(4, 2, 8, 8, generator=g)
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(x_all), y_all).backward()
+        opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_data_parallel_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, w0a, wa, ia), (_, w0b, wb, ib) = [(r, torch.from_numpy(a), torch.from_numpy(b), i) for r, a, b, i in res]
+    assert torch.equal(w0a, w0b), "broadcast_parameters did not synchronise the replicas"
+    assert torch.equal(wa, wb), "replicas diverged after all-reduced steps"
+    assert sorted(ia + ib) == [0, 1, 2, 3] and not set(ia) & set(ib)
+    # mean of per-shard mean losses == full-batch mean loss (equal shard sizes): same as one process
+    ref = _single_process_reference(w0a)
+    assert torch.allclose(wa, ref, atol=1e-6, rtol=1e-5)
+
+
+def test_flat_bucket_views_and_single_rank_noop():
+    from superresolution_amd.dp import FlatGradAllReducer
+    lin = torch.nn.Linear(3, 2)
+    red = FlatGradAllReducer(lin.parameters())
+    lin(torch.ones(1, 3)).sum().backward()
+    red.check_views()
+    assert red.flat.abs().sum() > 0
+    before = red.flat.clone()
+    red.all_reduce()
+    assert torch.equal(before, red.flat)
+    lin.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        red.check_views()
