@@ -8,6 +8,10 @@ A step = one forward pass over one frame whose inputs are already resident in HB
 ranks (one process per GPU, launched by torch.distributed.run) frames are sharded across ranks
 with no data-path collective (weak scaling); the value is whole-job frames/s.
 
+`--workload train` (BASELINE.json configs[2]): one step = nearest down-sampling of the aliased crops +
+forward + clip + L1 + 0.5*SSIM + backward + gradient all-reduce + AdamW on 16 HR crops of 1024x1024
+per GPU (core/trainer.py:143-161 with sequence length 1); the value is whole-job crops/s.
+
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the 64->64 3x3 MFMA
 convolution at 4K: 21 of the 25 HR layers), timed per launch with events on the launch stream;
 `cpu_baseline` times the CPU oracle on a bounded crop of the same workload on the host cores.
@@ -37,8 +41,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="infer4k", choices=["infer4k"])
+    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=16, help="crops per GPU per step (train workload)")
+    ap.add_argument("--train-crop", type=int, default=1024, help="HR crop size (train workload)")
+    ap.add_argument("--cpu-train-crop", type=int, default=512, help="HR crop size of the CPU-oracle training sample")
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[288, 384], help="LR crop (h w) of the CPU-oracle sample")
     return ap.parse_args()
 
@@ -57,7 +64,7 @@ def make_inputs(dev, rank):
     return lr.to(dev), hb.to(dev)
 
 
-def dominant_kernel_time_ms(model, lr, hb, frames):
+def dominant_kernel_time_ms(run_once, hr_h, frames):
     """Average duration of one launch of the plain 64->64 3x3 convolution at 4K as it runs inside
     the network (real activations), measured with events on the stream the kernel is launched on
     (torch's current stream): every such launch of `frames` extra forward passes is bracketed."""
@@ -66,7 +73,7 @@ def dominant_kernel_time_ms(model, lr, hb, frames):
     evs = []
 
     def timed(src_a, wpack, bias, cout, src_b=None, res=None, **kw):
-        hit = src_b is None and res is None and src_a.shape[-1] == 64 and cout == 64 and src_a.shape[1] == HR_H
+        hit = src_b is None and res is None and src_a.shape[-1] == 64 and cout == 64 and src_a.shape[1] == hr_h
         if not hit:
             return real(src_a, wpack, bias, cout, src_b=src_b, res=res, **kw)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -79,7 +86,7 @@ def dominant_kernel_time_ms(model, lr, hb, frames):
     F_.conv3x3 = timed
     try:
         for _ in range(frames):
-            model.infer(lr[:, -1], hb[:, -1])
+            run_once()
         torch.cuda.synchronize()
     finally:
         F_.conv3x3 = real
@@ -126,6 +133,113 @@ def cpu_baseline(crop):
                       f"scaled by pixel count to a 540x960 -> 2160x3840 frame"}
 
 
+def cpu_baseline_train(crop):
+    """Oracle forward + backward of the network (the loss gradient is a fixed tensor) on ONE HR crop,
+    scaled by pixel count to 1024x1024 crops/s."""
+    import numpy as np
+    from oracle import oracle as orc
+    from superresolution_amd import SuperSampler
+    cores = min(16, os.cpu_count() or 1)
+    orc.set_threads(cores)
+    torch.manual_seed(42)
+    sd = {k: v.numpy() for k, v in SuperSampler(3, 10, 1).state_dict().items()}
+    rng = np.random.default_rng(42)
+    lr = rng.random((1, 1, 3, crop // SCALE, crop // SCALE), dtype=np.float32)
+    hb = rng.random((1, 1, 10, crop, crop), dtype=np.float32)
+    dsr = (rng.random((1, 3, crop, crop), dtype=np.float32) - 0.5) / (3.0 * crop * crop)
+    orc.supersampler_forward_backward(sd, lr[..., :8, :8], hb[..., :32, :32], lambda sr: dsr[..., :32, :32])  # page in
+    t0 = time.perf_counter()
+    orc.supersampler_forward_backward(sd, lr, hb, lambda sr: dsr)
+    dt = time.perf_counter() - t0
+    return {"value": (crop * crop) / (1024.0 * 1024.0) / dt, "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"oracle forward + backward (loss and optimiser excluded) on one HR {crop}x{crop} crop ({dt:.2f} s), "
+                      f"scaled by pixel count to 1024x1024 crops"}
+
+
+def run_train(args, world, rank, dev, dist):
+    from superresolution_amd import functional as F_
+    from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters
+    from superresolution_amd.loss import LossGroup
+    B, S = args.train_batch, args.train_crop
+    model = make_model(dev).train()
+    broadcast_parameters(model, src=0)
+    red = FlatGradAllReducer(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)  # configs/trainer/4x_H2.yaml:12-17
+    loss_group = LossGroup(1.0, 0.5, report=False).to(dev)
+    g = torch.Generator().manual_seed(42 + rank)
+    alias = torch.rand(B, 1, 3, S, S, generator=g).to(dev)
+    target = torch.rand(B, 1, 3, S, S, generator=g).to(dev)
+    buffers = torch.rand(B, 1, 10, S, S, generator=g)
+    buffers[:, :, 9] *= 3.0
+    buffers = buffers.to(dev)
+
+    def step():
+        # core/trainer.py:86-113 (_make_inputs, scale 4) and :143-161 (one frame per clip)
+        lr = F_.nearest_down(alias.view(B, 3, S, S), 1.0 / SCALE).view(B, 1, 3, S // SCALE, S // SCALE)
+        batch = {"scale": float(SCALE), "hr_frames": target[:, 0], "lr_frames": lr, "hr_buffers": buffers}
+        batch = model(batch)
+        batch["sr_frames"] = torch.clip(batch["sr_frames"], min=0.0, max=10.0)
+        red.zero_grad()
+        loss, _ = loss_group(batch)
+        loss.backward()
+        red.all_reduce()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(loss))
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    p_hr, p_lr = B * S * S, B * (S // SCALE) ** 2
+    fwd = FLOP_PER_HR_PX * p_hr + FLOP_PER_LR_PX * p_lr
+    # backward = dgrad + wgrad of every layer except the data gradient of the two input layers
+    no_dgrad = 2 * 9 * (10 * 64 * p_hr + 3 * 32 * p_lr)
+    flop_step = 3 * fwd - no_dgrad
+    k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, S, 2)
+    k_flop = 2.0 * B * S * S * 64 * 64 * 9
+    achieved = k_flop / (k_avg_ms * 1e-3) / 1e12
+    res = {
+        "metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs",
+        "value": world * B * args.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"training step on {B} HR crops of {S}x{S} per GPU (LR {S // SCALE}x{S // SCALE}, scale 4): "
+                               "nearest down-sampling + forward + clip + L1 + 0.5*SSIM + backward + gradient all-reduce + AdamW, "
+                               "default SuperSampler, fp32 master weights",
+                   "crops_per_step_per_gpu": B, "tflop_per_step_per_gpu": flop_step / 1e12,
+                   "net_tflops_per_gpu": flop_step / 1e12 / (ms_per_step * 1e-3),
+                   "net_frac_of_bf16_mfma_peak": flop_step / 1e12 / (ms_per_step * 1e-3) / BF16_MFMA_PEAK_TFLOPS},
+        "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<Cfg<4,2,1,false,0>> (64->64 3x3 + bias + ReLU @ {B}x{S}x{S}; "
+                                                 "the same kernel runs every data gradient)",
+                     "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "avg_launch_ms": k_avg_ms, "median_launch_ms": k_med_ms, "launches_timed": k_launches,
+                     "algorithmic_flop_per_launch": k_flop,
+                     "algorithmic_bytes_per_launch": 2.0 * B * S * S * 64 * 2},
+    }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_train(args.cpu_train_crop)
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +251,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "train":
+        run_train(args, world, rank, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     model = make_model(dev)
     lr, hb = make_inputs(dev, rank)
@@ -168,7 +288,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         fps = world * args.steps / dt
         flop_frame = FLOP_PER_HR_PX * HR_H * HR_W + FLOP_PER_LR_PX * LR_H * LR_W
-        k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(model, lr, hb, 5)
+        k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, HR_H, 5)
         k_flop = 2.0 * HR_H * HR_W * 64 * 64 * 9
         achieved = k_flop / (k_avg_ms * 1e-3) / 1e12
         res = {

@@ -250,6 +250,74 @@ def supersampler_forward(sd, lr_frames, hr_buffers, return_intermediates=False):
     return sr
 
 
+def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn):
+    """Forward (core/models/model.py:147-175) and the backward ATen's autograd performs for it
+    (loss.backward(), core/trainer.py:160): returns (sr, grads) with grads keyed like the state
+    dict.  `dsr_fn(sr)` supplies dL/d(sr) (the loss itself is outside this restatement)."""
+    lr = _c(lr_frames[:, -1])
+    hb = _c(hr_buffers[:, -1])
+    th, tw = hb.shape[-2:]
+    grads = {}
+
+    def fwd(x, key, act=1):
+        return conv2d(x, sd[key + ".weight"], sd[key + ".bias"], 1, 1, act=act)
+
+    def bwd(x, y, dy, key, act=1, need_dx=True):
+        """x -> y = act(conv(x)); dy = dL/dy.  Accumulates parameter grads, returns dL/dx."""
+        dz = dy * (y > 0) if act == 1 else dy
+        dw, db = conv2d_bwd_weight(x, dz, sd[key + ".weight"].shape, padding=1)
+        grads[key + ".weight"] = dw
+        grads[key + ".bias"] = db
+        return conv2d_bwd_input(dz, sd[key + ".weight"], x.shape, padding=1) if need_dx else None
+
+    # ---- forward, keeping every activation
+    f = [lr]
+    for i in range(3):
+        f.append(fwd(f[-1], f"frame_extractor.blks.{i}.0"))
+    up = upsample_grid_bilinear(f[-1], th, tw)
+    gb, g = [], hb
+    for i in range(3):
+        x = fwd(g, f"gbuffers_extractor.blks.{2 * i}.0")
+        t1 = fwd(x, f"gbuffers_extractor.blks.{2 * i + 1}.0.0")
+        t2 = fwd(t1, f"gbuffers_extractor.blks.{2 * i + 1}.1.0")
+        gb.append((g, x, t1, t2))
+        g = x + t2
+    cat0 = np.concatenate((up, g), axis=1)
+    xs = [fwd(cat0, "main.conv_in.0")]
+    ts, us = [], []
+    for i in range(6):
+        ts.append(fwd(xs[-1], f"main.conv_main.{i}.blks.0"))
+        us.append(fwd(ts[-1], f"main.conv_main.{i}.blks.2", act=0))
+        xs.append(np.float32(0.2) * us[-1] + xs[-1])
+    cat1 = np.concatenate((up, xs[-1]), axis=1)
+    a = fwd(cat1, "after_main.0")
+    c0 = fwd(a, "final_conv.0")
+    sr = fwd(c0, "final_conv.2", act=0)
+
+    # ---- backward
+    d = bwd(c0, sr, _c(dsr_fn(sr)), "final_conv.2", act=0)
+    d = bwd(a, c0, d, "final_conv.0")
+    d = bwd(cat1, a, d, "after_main.0")
+    nf = up.shape[1]
+    dup, dx = d[:, :nf].copy(), d[:, nf:].copy()
+    for i in reversed(range(6)):
+        dt = bwd(ts[i], us[i], np.float32(0.2) * dx, f"main.conv_main.{i}.blks.2", act=0)
+        dx = dx + bwd(xs[i], ts[i], dt, f"main.conv_main.{i}.blks.0")
+    d = bwd(cat0, xs[0], dx, "main.conv_in.0")
+    dup += d[:, :nf]
+    dg = d[:, nf:].copy()
+    for i in reversed(range(3)):
+        prev, x, t1, t2 = gb[i]
+        dt1 = bwd(t1, t2, dg, f"gbuffers_extractor.blks.{2 * i + 1}.1.0")
+        dxb = dg + bwd(x, t1, dt1, f"gbuffers_extractor.blks.{2 * i + 1}.0.0")
+        dg = bwd(prev, x, dxb, f"gbuffers_extractor.blks.{2 * i}.0", need_dx=i > 0)
+    grid = np.broadcast_to(np.transpose(make_coord(th, tw), (0, 2, 3, 1)), (lr.shape[0], th, tw, 2)).copy()
+    d, _ = grid_sample_bwd(f[3], grid, dup, align_corners=False, need_dgrid=False)
+    for i in reversed(range(3)):
+        d = bwd(f[i], f[i + 1], d, f"frame_extractor.blks.{i}.0", need_dx=i > 0)
+    return sr, grads
+
+
 def reprfn_forward_deploy(sd, x):
     """core/arch/RepRFN.py:327-339 in deploy form (state dict after switch_to_deploy())."""
     def conv(x, key, stride=1, padding=1, act=0, slope=0.0):

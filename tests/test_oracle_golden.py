@@ -141,3 +141,27 @@ def test_reprfn_deploy_forward(reprfn_golden):
     y = orc.reprfn_forward_deploy(sd, z["net.x"])
     assert y.shape == z["net.y"].shape
     _close(y, z["net.y"], 2e-5)
+
+
+def test_supersampler_backward_golden(ss_golden):
+    """The oracle's forward+backward composition reproduces the reference's autograd gradients
+    (dL/d(sr) of L1 + 0.5*SSIM on the clipped output comes from torch's autograd of the loss mirror,
+    checked here against the golden loss value)."""
+    import torch
+    from superresolution_amd.loss import LossGroup
+    z, sd = ss_golden
+    info = {}
+
+    def dsr_fn(sr):
+        t = torch.from_numpy(sr).requires_grad_(True)
+        loss, ld = LossGroup(1.0, 0.5)({"hr_frames": torch.from_numpy(z["hr_frames"]), "sr_frames": torch.clip(t, 0.0, 10.0)})
+        loss.backward()
+        info.update(ld)
+        return t.grad.numpy()
+
+    sr, grads = orc.supersampler_forward_backward(sd, z["lr_frames"], z["hr_buffers"], dsr_fn)
+    assert np.abs(sr - z["sr_frames"]).max() <= 1e-4
+    assert abs(info["total"] - float(z["loss"])) <= 1e-5 and abs(info["ssim"] - float(z["loss_ssim"])) <= 1e-5
+    for k in sd:
+        ref = z["grad." + k]
+        assert np.abs(grads[k] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30) + 1e-9, k
