@@ -159,13 +159,13 @@ def cpu_baseline_train(crop):
 def run_train(args, world, rank, dev, dist):
     from superresolution_amd import functional as F_
     from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters
-    from superresolution_amd.loss import LossGroup
+    from superresolution_amd.loss import FusedLossGroup
     B, S = args.train_batch, args.train_crop
     model = make_model(dev).train()
     broadcast_parameters(model, src=0)
     red = FlatGradAllReducer(model.parameters())
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)  # configs/trainer/4x_H2.yaml:12-17
-    loss_group = LossGroup(1.0, 0.5, report=False).to(dev)
+    loss_group = FusedLossGroup(1.0, 0.5, clip=(0.0, 10.0), report=False)  # clip: core/trainer.py:154-156
     g = torch.Generator().manual_seed(42 + rank)
     alias = torch.rand(B, 1, 3, S, S, generator=g).to(dev)
     target = torch.rand(B, 1, 3, S, S, generator=g).to(dev)
@@ -178,7 +178,6 @@ def run_train(args, world, rank, dev, dist):
         lr = F_.nearest_down(alias.view(B, 3, S, S), 1.0 / SCALE).view(B, 1, 3, S // SCALE, S // SCALE)
         batch = {"scale": float(SCALE), "hr_frames": target[:, 0], "lr_frames": lr, "hr_buffers": buffers}
         batch = model(batch)
-        batch["sr_frames"] = torch.clip(batch["sr_frames"], min=0.0, max=10.0)
         red.zero_grad()
         loss, _ = loss_group(batch)
         loss.backward()

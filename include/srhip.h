@@ -168,6 +168,19 @@ SRHIP_API int srhip_upsample_grid_bilinear_bwd_nhwc(const void* ddst, const void
 SRHIP_API int srhip_relu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, void* stream);
 SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t count, void* stream);
 
+/* Fused loss of the default trainer configuration, forward AND backward in one call:
+ *   xc   = clamp(sr, clip_min, clip_max)                       (core/trainer.py:154-156)
+ *   loss = lambda_l1 * mean|xc - y| + lambda_ssim * (1 - SSIM(xc, y))
+ * (LossGroup core/models/model.py:183-207; SSIMLoss core/modules/loss.py:12-29; _ssim
+ * core/modules/functional.py:169-189: 11x11 Gaussian window, sigma 1.5, zero padding.)
+ * sr, target, dsr: (planes, h, w) fp32 (planes = batch * channels); dsr = dloss/dsr;
+ * out3 (device) = {l1, ssim_loss, total}.  Pass -INFINITY/+INFINITY to disable the clip.
+ * workspace: srhip_l1_ssim_workspace_bytes(planes, h, w) bytes, caller-owned. */
+SRHIP_API size_t srhip_l1_ssim_workspace_bytes(int planes, int h, int w);
+SRHIP_API int srhip_l1_ssim_loss(const float* sr, const float* target, float* dsr, float* out3,
+                                 void* workspace, int planes, int h, int w, float lambda_l1,
+                                 float lambda_ssim, float clip_min, float clip_max, void* stream);
+
 /* Motion-vector backward warp, core/tools/math.py:10-17 (grid (x,y)-last as the
  * function evidently intends): frame (N,C,h,w), motion (N,2,h,w) in pixels,
  * zero padding.  fp32 NCHW in/out. */

@@ -1,0 +1,247 @@
+// Fused L1 + SSIM loss, forward and backward, for gfx950.
+//
+// Replaces LossGroup.forward + loss.backward() of the default trainer configuration
+// (core/models/model.py:183-207; SSIMLoss core/modules/loss.py:12-29; _ssim
+// core/modules/functional.py:169-189) together with the pixel clip in front of it
+// (core/trainer.py:154-156):
+//
+//   xc   = clamp(sr, clip_min, clip_max)
+//   loss = lambda_l1 * mean|xc - y| + lambda_ssim * (1 - mean(ssim_map(xc, y)))
+//
+// ssim_map uses five 11x11 Gaussian (sigma 1.5) depthwise filters with zero padding:
+// mu_x, mu_y, E[x^2], E[y^2], E[xy].  The window is an outer product, so the filters run as a
+// horizontal and a vertical 11-tap pass through LDS.  Because the loss is a mean, dL/d(ssim_map)
+// and dL/d|xc-y| are constants known up front, so the backward needs no second look at the loss:
+//
+//   pass 1 (ssim_fwd_kernel):  per pixel S and a = dS/dmu_x, b = dS/dE[x^2], c = dS/dE[xy];
+//                              block sums of S and |xc-y| -> partials;  a, b, c -> workspace
+//   pass 2 (ssim_bwd_kernel):  dsr = clipmask * ( -ls/N * (G*a + 2 xc (G*b) + y (G*c))
+//                                                 + l1/N * sign(xc - y) )
+//   finalize: sums the partials in a fixed order -> out[3] = {l1, ssim_loss, total}
+//
+// HBM-bound: 2 + 3 reads/writes in pass 1, 5 + 1 in pass 2 = 11 floats per pixel.
+#include "srhip_common.h"
+
+namespace {
+
+constexpr int WIN = 11, HALO = 5, TILE = 32, EXT = TILE + 2 * HALO;  // 42
+
+struct Gauss { float w[WIN]; };
+
+struct LossParams {
+    const float* sr;
+    const float* y;
+    float* abc;      // workspace: 3 maps of planes*h*w floats
+    float* partial;  // workspace: 2 floats per block
+    float* dsr;
+    int planes, h, w, tiles_x, tiles_y;
+    float clip_min, clip_max;
+    float g_ssim, g_l1;  // -lambda_ssim / N,  lambda_l1 / N
+    Gauss g;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const LossParams p)
+{
+    __shared__ float sx[EXT][EXT + 1], sy[EXT][EXT + 1];
+    __shared__ float hb[5][EXT][TILE + 1];
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int plane = b / p.tiles_y;
+    const int x0 = tx * TILE, y0 = ty * TILE;
+    const long long base = (long long)plane * p.h * p.w;
+
+    for (int i = tid; i < EXT * EXT; i += 256) {
+        const int r = i / EXT, c = i % EXT;
+        const int yy = y0 - HALO + r, xx = x0 - HALO + c;
+        float vx = 0.0f, vy = 0.0f;
+        if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
+            vx = clampf(p.sr[base + (long long)yy * p.w + xx], p.clip_min, p.clip_max);
+            vy = p.y[base + (long long)yy * p.w + xx];
+        }
+        sx[r][c] = vx; sy[r][c] = vy;
+    }
+    __syncthreads();
+    // horizontal pass: EXT rows x TILE columns, five quantities
+    for (int i = tid; i < EXT * TILE; i += 256) {
+        const int r = i / TILE, c = i % TILE;
+        float q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float g = p.g.w[k], vx = sx[r][c + k], vy = sy[r][c + k];
+            q0 += g * vx; q1 += g * vy; q2 += g * vx * vx; q3 += g * vy * vy; q4 += g * vx * vy;
+        }
+        hb[0][r][c] = q0; hb[1][r][c] = q1; hb[2][r][c] = q2; hb[3][r][c] = q3; hb[4][r][c] = q4;
+    }
+    __syncthreads();
+    float s_sum = 0.0f, l_sum = 0.0f;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    for (int i = tid; i < TILE * TILE; i += 256) {
+        const int r = i / TILE, c = i % TILE;
+        const int yy = y0 + r, xx = x0 + c;
+        if (yy >= p.h || xx >= p.w) continue;
+        float mx = 0, my = 0, exx = 0, eyy = 0, exy = 0;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float g = p.g.w[k];
+            mx += g * hb[0][r + k][c]; my += g * hb[1][r + k][c];
+            exx += g * hb[2][r + k][c]; eyy += g * hb[3][r + k][c]; exy += g * hb[4][r + k][c];
+        }
+        const float mx2 = mx * mx, my2 = my * my, mxy = mx * my;
+        const float A1 = 2.0f * mxy + C1, A2 = 2.0f * (exy - mxy) + C2;
+        const float B1 = mx2 + my2 + C1, B2 = (exx - mx2) + (eyy - my2) + C2;
+        const float inv = 1.0f / (B1 * B2);
+        const float S = A1 * A2 * inv;
+        const float da = 2.0f * my * (A2 - A1) * inv - S * 2.0f * mx * (B2 - B1) * inv;
+        const float db = -S / B2;
+        const float dc = 2.0f * A1 * inv;
+        const long long o = base + (long long)yy * p.w + xx;
+        const long long map = (long long)p.planes * p.h * p.w;
+        p.abc[o] = da; p.abc[map + o] = db; p.abc[2 * map + o] = dc;
+        s_sum += S;
+        l_sum += fabsf(sx[r + HALO][c + HALO] - sy[r + HALO][c + HALO]);
+    }
+    // block reduction in a fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s_sum += __shfl_down(s_sum, off);
+        l_sum += __shfl_down(l_sum, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s_sum; red[1][tid >> 6] = l_sum; }
+    __syncthreads();
+    if (tid == 0) {
+        p.partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p.partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const LossParams p)
+{
+    __shared__ float sm[3][EXT][EXT + 1];
+    __shared__ float hb[3][EXT][TILE + 1];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int plane = b / p.tiles_y;
+    const int x0 = tx * TILE, y0 = ty * TILE;
+    const long long base = (long long)plane * p.h * p.w;
+    const long long map = (long long)p.planes * p.h * p.w;
+    for (int i = tid; i < EXT * EXT; i += 256) {
+        const int r = i / EXT, c = i % EXT;
+        const int yy = y0 - HALO + r, xx = x0 - HALO + c;
+        float a = 0.0f, bb = 0.0f, cc = 0.0f;
+        if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
+            const long long o = base + (long long)yy * p.w + xx;
+            a = p.abc[o]; bb = p.abc[map + o]; cc = p.abc[2 * map + o];
+        }
+        sm[0][r][c] = a; sm[1][r][c] = bb; sm[2][r][c] = cc;
+    }
+    __syncthreads();
+    for (int i = tid; i < EXT * TILE; i += 256) {
+        const int r = i / TILE, c = i % TILE;
+        float q0 = 0, q1 = 0, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float g = p.g.w[k];
+            q0 += g * sm[0][r][c + k]; q1 += g * sm[1][r][c + k]; q2 += g * sm[2][r][c + k];
+        }
+        hb[0][r][c] = q0; hb[1][r][c] = q1; hb[2][r][c] = q2;
+    }
+    __syncthreads();
+    for (int i = tid; i < TILE * TILE; i += 256) {
+        const int r = i / TILE, c = i % TILE;
+        const int yy = y0 + r, xx = x0 + c;
+        if (yy >= p.h || xx >= p.w) continue;
+        float ga = 0, gb = 0, gc = 0;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float g = p.g.w[k];
+            ga += g * hb[0][r + k][c]; gb += g * hb[1][r + k][c]; gc += g * hb[2][r + k][c];
+        }
+        const long long o = base + (long long)yy * p.w + xx;
+        const float raw = p.sr[o], yv = p.y[o];
+        const float xc = clampf(raw, p.clip_min, p.clip_max);
+        const float diff = xc - yv;
+        const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+        float d = p.g_ssim * (ga + 2.0f * xc * gb + yv * gc) + p.g_l1 * sgn;
+        if (!(raw >= p.clip_min && raw <= p.clip_max)) d = 0.0f;  // clamp backward
+        p.dsr[o] = d;
+    }
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nblocks, float inv_n, float lambda_l1,
+                                     float lambda_ssim, float* __restrict__ out)
+{
+    __shared__ double rs[256], rl[256];
+    double s = 0.0, l = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { s += partial[2 * i]; l += partial[2 * i + 1]; }
+    rs[threadIdx.x] = s; rl[threadIdx.x] = l;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rl[threadIdx.x] += rl[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l1 = (float)(rl[0] * inv_n);
+        const float ssim = 1.0f - (float)(rs[0] * inv_n);
+        out[0] = l1; out[1] = ssim; out[2] = lambda_l1 * l1 + lambda_ssim * ssim;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+SRHIP_API size_t srhip_l1_ssim_workspace_bytes(int planes, int h, int w)
+{
+    const size_t px = (size_t)planes * h * w;
+    const size_t blocks = (size_t)planes * srhip_div_up(h, TILE) * srhip_div_up(w, TILE);
+    return (3 * px + 2 * blocks) * sizeof(float);
+}
+
+SRHIP_API int srhip_l1_ssim_loss(const float* sr, const float* target, float* dsr, float* out3, void* workspace,
+                                 int planes, int h, int w, float lambda_l1, float lambda_ssim, float clip_min,
+                                 float clip_max, void* stream)
+{
+    SRHIP_REQUIRE(sr && target && dsr && out3 && workspace, "l1_ssim_loss: null pointer");
+    SRHIP_REQUIRE(planes >= 1 && h >= 1 && w >= 1, "l1_ssim_loss: empty tensor");
+    SRHIP_REQUIRE(clip_min <= clip_max, "l1_ssim_loss: clip_min > clip_max");
+    LossParams p;
+    p.sr = sr; p.y = target; p.dsr = dsr;
+    p.planes = planes; p.h = h; p.w = w;
+    p.tiles_x = srhip_div_up(w, TILE); p.tiles_y = srhip_div_up(h, TILE);
+    const long long nblocks = (long long)planes * p.tiles_x * p.tiles_y;
+    SRHIP_REQUIRE(nblocks < (1ll << 31), "l1_ssim_loss: too many tiles");
+    const size_t px = (size_t)planes * h * w;
+    p.abc = (float*)workspace;
+    p.partial = p.abc + 3 * px;
+    p.clip_min = clip_min; p.clip_max = clip_max;
+    const double n = (double)px;
+    p.g_ssim = (float)(-(double)lambda_ssim / n);
+    p.g_l1 = (float)((double)lambda_l1 / n);
+    // core/modules/functional.py:6-9 in fp32: exp(-(i - 5)^2 / (2 sigma^2)), normalised by its sum
+    float gs[WIN], sum = 0.0f;
+    for (int i = 0; i < WIN; ++i) {
+        const float d = (float)(i - WIN / 2);
+        gs[i] = expf(-(d * d) / (2.0f * 1.5f * 1.5f));
+        sum += gs[i];
+    }
+    for (int i = 0; i < WIN; ++i) p.g.w[i] = gs[i] / sum;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, p);
+    int rc = srhip_check_launch("ssim_fwd_kernel");
+    if (rc != SRHIP_OK) return rc;
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, p);
+    rc = srhip_check_launch("ssim_bwd_kernel");
+    if (rc != SRHIP_OK) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, p.partial, (int)nblocks, (float)(1.0 / n), lambda_l1,
+                       lambda_ssim, out3);
+    return srhip_check_launch("loss_finalize_kernel");
+}
+
+}  // extern "C"

@@ -179,6 +179,23 @@ def upsample_grid_bilinear_bwd_nhwc(dy: torch.Tensor, sh: int, sw: int, relu_out
     return out
 
 
+def l1_ssim_loss(sr: torch.Tensor, target: torch.Tensor, lambda_l1: float, lambda_ssim: float,
+                 clip_min: float = float("-inf"), clip_max: float = float("inf")):
+    """Fused clip + L1 + SSIM loss and its gradient: returns (out3, dsr) with out3 = [l1, ssim_loss, total]
+    (device tensor) and dsr = d total / d sr."""
+    sr = _req(sr, torch.float32, "sr")
+    target = _req(target, torch.float32, "target")
+    if sr.shape != target.shape or sr.dim() != 4:
+        raise ValueError("l1_ssim_loss: sr and target must be equal-shape (N,C,H,W) tensors")
+    n, c, h, w = sr.shape
+    ws = torch.empty((lib.srhip_l1_ssim_workspace_bytes(n * c, h, w),), dtype=torch.uint8, device=sr.device)
+    dsr = torch.empty_like(sr)
+    out3 = torch.empty((3,), dtype=torch.float32, device=sr.device)
+    check(lib.srhip_l1_ssim_loss(sr.data_ptr(), target.data_ptr(), dsr.data_ptr(), out3.data_ptr(), ws.data_ptr(), n * c, h, w,
+                                 lambda_l1, lambda_ssim, clip_min, clip_max, _stream()))
+    return out3, dsr
+
+
 def conv2d_direct(src: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], cin: int, stride=1, padding=0,
                   res: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0, alpha: float = 1.0,
                   cout_stride: Optional[int] = None) -> torch.Tensor:

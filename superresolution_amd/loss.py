@@ -2,10 +2,12 @@
 (core/models/model.py:183-207) with ``SSIMLoss`` (core/modules/loss.py:12-29,
 core/modules/functional.py:6-9,169-189): ``lambda_l1 * L1 + lambda_ssim * (1 - SSIM)``.
 
-It is the step right after the network in every training step.  It runs on torch operators (five
-depthwise 11x11 Gaussian filters on 3-channel images + an element-wise map), exactly the
-reference's formulation; only the host synchronisations differ: the three ``.item()`` calls of the
-reference become one optional transfer.
+It is the step right after the network in every training step.  ``LossGroup`` is the reference's
+formulation on torch operators (five depthwise 11x11 Gaussian filters + an element-wise map) and
+runs anywhere; ``FusedLossGroup`` computes the same value and its gradient in one HIP call
+(two tiled separable-filter passes) and can fold the trainer's pixel clip
+(core/trainer.py:154-156) in.  The three ``.item()`` synchronisations of the reference become one
+optional transfer.
 """
 from typing import Dict, Tuple
 
@@ -58,5 +60,39 @@ class LossGroup(nn.Module):
         loss_dict = {}
         if self.report:  # one device->host transfer instead of three
             v = torch.stack((l1.detach(), ssim.detach(), loss.detach())).tolist()
+            loss_dict = {"l1": v[0], "ssim": v[1], "total": v[2]}
+        return loss, loss_dict
+
+
+class _FusedL1SSIMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sr: Tensor, target: Tensor, lambda_l1: float, lambda_ssim: float, lo: float, hi: float):
+        from . import functional as F_
+        out3, dsr = F_.l1_ssim_loss(sr, target, lambda_l1, lambda_ssim, lo, hi)
+        ctx.dsr = dsr
+        ctx.mark_non_differentiable(out3)
+        return out3[2].clone(), out3
+
+    @staticmethod
+    def backward(ctx, g_total: Tensor, _g_parts):
+        dsr, ctx.dsr = ctx.dsr, None
+        return dsr * g_total, None, None, None, None, None
+
+
+class FusedLossGroup(nn.Module):
+    """Same interface and value as ``LossGroup`` on GPU tensors; ``clip=(lo, hi)`` additionally applies
+    ``torch.clip(sr, lo, hi)`` (and its backward) inside the kernel, so the caller passes the raw output."""
+
+    def __init__(self, lambda_l1: float, lambda_ssim: float, clip=None, report: bool = True) -> None:
+        super().__init__()
+        self.lambda_l1, self.lambda_ssim, self.report = lambda_l1, lambda_ssim, report
+        self.clip = (float("-inf"), float("inf")) if clip is None else (float(clip[0]), float(clip[1]))
+
+    def forward(self, batch) -> Tuple[Tensor, Dict[str, float]]:
+        loss, parts = _FusedL1SSIMFn.apply(batch["sr_frames"], batch["hr_frames"], self.lambda_l1, self.lambda_ssim,
+                                           self.clip[0], self.clip[1])
+        loss_dict = {}
+        if self.report:
+            v = parts.tolist()
             loss_dict = {"l1": v[0], "ssim": v[1], "total": v[2]}
         return loss, loss_dict

@@ -165,3 +165,15 @@ def test_supersampler_backward_golden(ss_golden):
     for k in sd:
         ref = z["grad." + k]
         assert np.abs(grads[k] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30) + 1e-9, k
+
+
+def test_loss_mirror_golden(ss_golden):
+    """The torch formulation of LossGroup (the checker of the fused GPU loss) reproduces the loss values the
+    reference computed on its own output."""
+    import torch
+    from superresolution_amd.loss import LossGroup
+    z, _ = ss_golden
+    loss, d = LossGroup(1.0, 0.5)({"hr_frames": torch.from_numpy(z["hr_frames"]),
+                                   "sr_frames": torch.clip(torch.from_numpy(z["sr_frames"]), 0.0, 10.0)})
+    assert abs(d["total"] - float(z["loss"])) <= 1e-6
+    assert abs(d["l1"] - float(z["loss_l1"])) <= 1e-6 and abs(d["ssim"] - float(z["loss_ssim"])) <= 1e-6
