@@ -168,6 +168,17 @@ SRHIP_API int srhip_upsample_grid_bilinear_bwd_nhwc(const void* ddst, const void
 SRHIP_API int srhip_relu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, void* stream);
 SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t count, void* stream);
 
+/* ESA attention helpers of RepRFN (core/arch/RepRFN.py:295-308) on NHWC bf16, c % 8 == 0:
+ *   max_pool2d:      F.max_pool2d(x, kernel_size=k, stride=s)  (no padding)       :298
+ *   resize_bilinear: F.interpolate(x, (ho,wo), mode="bilinear", align_corners=False) + addend
+ *                    (addend (N,ho,wo,c) or NULL; the reference adds conv_f(c1_))  :303,305
+ *   sigmoid_gate:    dst = x * sigmoid(gate)                                       :306-308 */
+SRHIP_API int srhip_max_pool2d_nhwc(const void* src, void* dst, int n, int c, int h, int w, int k, int s,
+                                    void* stream);
+SRHIP_API int srhip_resize_bilinear_nhwc(const void* src, const void* addend, void* dst, int n, int c,
+                                         int h, int w, int ho, int wo, void* stream);
+SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst, size_t count, void* stream);
+
 /* Fused loss of the default trainer configuration, forward AND backward in one call:
  *   xc   = clamp(sr, clip_min, clip_max)                       (core/trainer.py:154-156)
  *   loss = lambda_l1 * mean|xc - y| + lambda_ssim * (1 - SSIM(xc, y))

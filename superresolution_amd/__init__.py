@@ -8,5 +8,6 @@ CPU fallback: importing the operators without the built library raises.
 from . import _lib  # noqa: F401  (loads libsrhip.so, raises if it is missing)
 from . import functional  # noqa: F401
 from .model import SuperSampler  # noqa: F401
+from .reprfn import RepRFN  # noqa: F401
 
-__all__ = ["functional", "SuperSampler"]
+__all__ = ["functional", "SuperSampler", "RepRFN"]

@@ -229,6 +229,95 @@ __global__ void add_bf16_kernel(const uint4* __restrict__ a, const uint4* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// ESA helpers (core/arch/RepRFN.py:295-308) on NHWC bf16: one thread = one output pixel x 8 channels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4 v, float* f)
+{
+    f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+    f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f)
+{
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+__global__ void max_pool_nhwc_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int n, int c,
+                                     int h, int w, int ho, int wo, int k, int s)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * ho * wo * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int ox = (int)(p % wo); p /= wo;
+        const int oy = (int)(p % ho);
+        const int img = (int)(p / ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx) {
+                float v[8];
+                unpack8(*(const uint4*)(src + (((long long)img * h + oy * s + ky) * w + ox * s + kx) * c + g * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > m[e] || v[e] != v[e]) m[e] = v[e];
+            }
+        *(uint4*)(dst + (((long long)img * ho + oy) * wo + ox) * c + g * 8) = pack8(m);
+    }
+}
+// F.interpolate(size=(ho,wo), mode="bilinear", align_corners=False) (+ optional addend of the output shape)
+__global__ void resize_bilinear_nhwc_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ addend,
+                                            unsigned short* __restrict__ dst, int n, int c, int h, int w, int ho, int wo)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * ho * wo * cg;
+    const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int ox = (int)(p % wo); p /= wo;
+        const int oy = (int)(p % ho);
+        const int img = (int)(p / ho);
+        float fy = __fsub_rn(__fmul_rn(sy, (float)oy + 0.5f), 0.5f);
+        float fx = __fsub_rn(__fmul_rn(sx, (float)ox + 0.5f), 0.5f);
+        if (fy < 0.0f) fy = 0.0f;
+        if (fx < 0.0f) fx = 0.0f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, hy = 1.0f - ly, lx = fx - (float)x0, hx = 1.0f - lx;
+        const unsigned short* ip = src + (long long)img * h * w * c + g * 8;
+        float a[8], b[8], cc[8], d[8], o[8];
+        unpack8(*(const uint4*)(ip + ((long long)y0 * w + x0) * c), a);
+        unpack8(*(const uint4*)(ip + ((long long)y0 * w + x1) * c), b);
+        unpack8(*(const uint4*)(ip + ((long long)y1 * w + x0) * c), cc);
+        unpack8(*(const uint4*)(ip + ((long long)y1 * w + x1) * c), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = hy * (hx * a[e] + lx * b[e]) + ly * (hx * cc[e] + lx * d[e]);
+        const long long off = (((long long)img * ho + oy) * wo + ox) * c + g * 8;
+        if (addend != nullptr) {
+            float t[8];
+            unpack8(*(const uint4*)(addend + off), t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += t[e];
+        }
+        *(uint4*)(dst + off) = pack8(o);
+    }
+}
+// dst = x * sigmoid(gate)
+__global__ void sigmoid_gate_kernel(const uint4* __restrict__ x, const uint4* __restrict__ gate, uint4* __restrict__ dst,
+                                    long long nvec)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(x[i], a);
+        unpack8(gate[i], b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = a[e] * (1.0f / (1.0f + expf(-b[e])));
+        dst[i] = pack8(a);
+    }
+}
+
 __global__ void warp_nhwc_kernel(const unsigned short* __restrict__ frame, const float* __restrict__ motion,
                                  unsigned short* __restrict__ dst, int n, int c, int h, int w, int mode, int align)
 {
@@ -689,6 +778,39 @@ SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t cou
     hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4*)a, (const uint4*)b, (uint4*)dst, nvec);
     return srhip_check_launch("add_bf16");
+}
+
+SRHIP_API int srhip_max_pool2d_nhwc(const void* src, void* dst, int n, int c, int h, int w, int k, int s, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "max_pool2d_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && k >= 1 && s >= 1 && h >= k && w >= k, "max_pool2d_nhwc: bad shape (c %% 8 == 0, window inside the image)");
+    const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
+    const long long work = (long long)n * ho * wo * (c / 8);
+    hipLaunchKernelGGL(max_pool_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, (unsigned short*)dst, n, c, h, w, ho, wo, k, s);
+    return srhip_check_launch("max_pool2d_nhwc");
+}
+
+SRHIP_API int srhip_resize_bilinear_nhwc(const void* src, const void* addend, void* dst, int n, int c, int h, int w, int ho,
+                                         int wo, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "resize_bilinear_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && h >= 1 && w >= 1 && ho >= 1 && wo >= 1, "resize_bilinear_nhwc: bad shape (c %% 8 == 0)");
+    const long long work = (long long)n * ho * wo * (c / 8);
+    hipLaunchKernelGGL(resize_bilinear_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, (const unsigned short*)addend, (unsigned short*)dst, n, c, h, w, ho, wo);
+    return srhip_check_launch("resize_bilinear_nhwc");
+}
+
+SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst, size_t count, void* stream)
+{
+    SRHIP_REQUIRE(x && gate && dst, "sigmoid_gate_bf16: null pointer");
+    SRHIP_REQUIRE(count % 8 == 0, "sigmoid_gate_bf16: count must be a multiple of 8");
+    if (count == 0) return SRHIP_OK;
+    const long long nvec = (long long)(count / 8);
+    hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)x, (const uint4*)gate, (uint4*)dst, nvec);
+    return srhip_check_launch("sigmoid_gate_bf16");
 }
 
 SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t pixels, int ca, int cb, void* stream)

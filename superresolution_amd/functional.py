@@ -179,6 +179,37 @@ def upsample_grid_bilinear_bwd_nhwc(dy: torch.Tensor, sh: int, sw: int, relu_out
     return out
 
 
+def max_pool2d_nhwc(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
+    x = _req(x, torch.bfloat16, "x")
+    n, h, w, c = x.shape
+    out = torch.empty((n, (h - k) // s + 1, (w - k) // s + 1, c), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_max_pool2d_nhwc(x.data_ptr(), out.data_ptr(), n, c, h, w, k, s, _stream()))
+    return out
+
+
+def resize_bilinear_nhwc(x: torch.Tensor, ho: int, wo: int, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.interpolate(x, (ho, wo), mode="bilinear", align_corners=False) (+ addend) on NHWC bf16."""
+    x = _req(x, torch.bfloat16, "x")
+    n, h, w, c = x.shape
+    if addend is not None:
+        addend = _req(addend, torch.bfloat16, "addend")
+        if tuple(addend.shape) != (n, ho, wo, c):
+            raise ValueError("resize_bilinear_nhwc: addend must have the output shape")
+    out = torch.empty((n, ho, wo, c), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_resize_bilinear_nhwc(x.data_ptr(), _ptr(addend), out.data_ptr(), n, c, h, w, ho, wo, _stream()))
+    return out
+
+
+def sigmoid_gate(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    x = _req(x, torch.bfloat16, "x")
+    gate = _req(gate, torch.bfloat16, "gate")
+    if x.shape != gate.shape:
+        raise ValueError("sigmoid_gate: shapes differ")
+    out = torch.empty_like(x)
+    check(lib.srhip_sigmoid_gate_bf16(x.data_ptr(), gate.data_ptr(), out.data_ptr(), x.numel(), _stream()))
+    return out
+
+
 def l1_ssim_loss(sr: torch.Tensor, target: torch.Tensor, lambda_l1: float, lambda_ssim: float,
                  clip_min: float = float("-inf"), clip_max: float = float("inf")):
     """Fused clip + L1 + SSIM loss and its gradient: returns (out3, dsr) with out3 = [l1, ssim_loss, total]

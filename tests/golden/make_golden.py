@@ -287,9 +287,30 @@ def gen_reprfn():
     print("reprfn.npz: y mean", y.abs().mean().item(), "params", sum(p.numel() for p in m.parameters()))
 
 
+def gen_reprfn_init():
+    """Digest of the seed-42 initialisation of RepRFN in its training form (first 8 values + fp64 sum
+    of every state-dict entry) and the key lists of both forms."""
+    from core.arch.RepRFN import RepRFN
+    torch.manual_seed(42)
+    m = RepRFN(3, 3, 48, 4, deploy=False)
+    out = {"train.keys": np.array(list(m.state_dict().keys()))}
+    for name, p in m.state_dict().items():
+        v = p.detach().reshape(-1)
+        out["init." + name] = np.concatenate([v[:8].numpy(), np.array([v.double().sum().item()], np.float32)]).astype(np.float32)
+        out["shape." + name] = np.array(p.shape, np.int64)
+    d = RepRFN(3, 3, 48, 4, deploy=True)
+    out["deploy.keys"] = np.array(list(d.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "reprfn_init.npz"), **out)
+    print("reprfn_init.npz:", len(out["train.keys"]), "train keys,", len(out["deploy.keys"]), "deploy keys")
+
+
 if __name__ == "__main__":
     _stub_modules()
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "reprfn_init":
+        gen_reprfn_init()
+        sys.exit(0)
     gen_ops()
     gen_supersampler()
     gen_reprfn()
+    gen_reprfn_init()

@@ -1,0 +1,74 @@
+"""Host-side contract of the RepRFN mirror (no GPU): state-dict keys/shapes of both forms, the
+seed-for-seed initialisation and the RepBlock re-parameterisation, against fixtures produced by
+the reference (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def init_golden():
+    return np.load(os.path.join(GOLDEN, "reprfn_init.npz"))
+
+
+def test_state_dict_keys_and_shapes_both_forms(init_golden):
+    from superresolution_amd.reprfn import RepRFN
+    z = init_golden
+    m = RepRFN(3, 3, 48, 4, deploy=False)
+    assert list(m.state_dict().keys()) == [str(k) for k in z["train.keys"]]
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(z["shape." + k]), k
+    d = RepRFN(3, 3, 48, 4, deploy=True)
+    assert list(d.state_dict().keys()) == [str(k) for k in z["deploy.keys"]]
+
+
+def test_seed_for_seed_initialisation(init_golden):
+    from superresolution_amd.reprfn import RepRFN
+    z = init_golden
+    torch.manual_seed(42)
+    m = RepRFN(3, 3, 48, 4, deploy=False)
+    for k, v in m.state_dict().items():
+        ref = z["init." + k]
+        flat = v.detach().reshape(-1)
+        assert np.array_equal(flat[:8].numpy(), ref[:-1][:flat.numel()]), k
+        assert abs(flat.double().sum().item() - float(ref[-1])) <= 1e-5 * max(1.0, abs(float(ref[-1]))), k
+
+
+def test_repblock_reparameterisation_golden():
+    from superresolution_amd.reprfn import RepBlock
+    z = np.load(os.path.join(GOLDEN, "reprfn.npz"))
+    blk = RepBlock(48, 48, "lrelu", deploy=False)
+    assert list(blk.state_dict().keys()) == [str(k) for k in z["blk.keys"]]
+    blk.load_state_dict({str(k): torch.from_numpy(z["blk.sd." + str(k)]) for k in z["blk.keys"]}, strict=True)
+    k, b = blk.get_equivalent_kernel_bias()
+    assert np.abs(k.numpy() - z["blk.k"]).max() <= 1e-6
+    assert np.abs(b.numpy() - z["blk.b"]).max() <= 1e-6
+    # the reference's nine-branch forward equals one 3x3 with that kernel (RepRFN.py:183-191 vs :185)
+    from oracle import oracle as orc
+    y = orc.conv2d(z["blk.x"], k.numpy(), b.numpy(), 1, 1, act=2, slope=0.05)
+    assert np.abs(y - z["blk.y"]).max() <= 2e-5
+    blk.switch_to_deploy()
+    assert list(blk.state_dict().keys()) == ["rbr_reparam.weight", "rbr_reparam.bias"]
+    assert torch.equal(blk.rbr_reparam.weight, k)
+
+
+def test_switch_to_deploy_yields_deploy_state_dict(init_golden):
+    from superresolution_amd.reprfn import RepRFN
+    m = RepRFN(3, 3, 48, 4, deploy=False)
+    for mod in m.modules():
+        if hasattr(mod, "switch_to_deploy"):
+            mod.switch_to_deploy()
+    assert list(m.state_dict().keys()) == [str(k) for k in init_golden["deploy.keys"]]
+    d = RepRFN(3, 3, 48, 4, deploy=True)
+    d.load_state_dict(m.state_dict(), strict=True)
+
+
+def test_forward_with_grad_raises():
+    from superresolution_amd.reprfn import RepRFN
+    m = RepRFN(deploy=True)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 8, 8))
