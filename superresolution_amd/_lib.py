@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrhip.so")
+# SRHIP_LIBRARY selects another build of the same ABI (kernel experiments); default: the in-tree library
+LIB_PATH = os.environ.get("SRHIP_LIBRARY") or os.path.join(_HERE, "libsrhip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

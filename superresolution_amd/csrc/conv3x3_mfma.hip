@@ -115,7 +115,8 @@ struct Cfg {
     static constexpr int NFRAG = 9 * KC * NCT;                      // weight fragments per wave
     static constexpr int NFA_MAX = (256 - 16 * NCT) / 4;            // AGPR room beside the accumulators
     static constexpr int NFA = NFRAG < NFA_MAX ? NFRAG : NFA_MAX;   // fragments pinned to AGPRs
-    static constexpr int LDS_BYTES = RING_BYTES + NWAVES * STAGE_BYTES;
+    static constexpr int DUMMY_OFF = RING_BYTES + NWAVES * STAGE_BYTES;  // 1 KiB sink of the DMA pieces a wave does not own
+    static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
     static constexpr int MPT = KC * NCT;                            // MFMAs per tap
     // micro-steps run between the MFMAs of tap t (they belong to the PREVIOUS row's epilogue, except
     // tap 0 which issues this row's residual loads and the LDS-DMA pieces of row i+LA):
@@ -291,9 +292,6 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             rd[kx][s] = (unsigned)(C::sub_off(s) + px * C::cpp(s) * 16 + ((hl ^ f) << 4));
         }
 
-    // LDS-DMA pieces this wave issues per row (wave-uniform): MAXP or MAXP - 1
-    const int my_pieces = (C::NPIECE - wave + C::NWAVES - 1) / C::NWAVES;
-
     const int H = p.h, W = p.w;
     // source of sub-image s: KC == 6 is concat(A: 32 ch, B: 64 ch); KC == 3 is one 48-channel tensor
     const int csrc0 = p.ca, csrc1 = (C::KC == 6) ? p.cb : p.ca;
@@ -363,19 +361,32 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             vox[k] = (xq < W && ch < p.cout_stride) ? (unsigned)((xq * p.cout_stride + ch) * 2) : kOobOffset;
         }
 
-        // LDS-DMA piece m of input row r (scalar row offsets; rows outside the image / item read zeros)
-        auto issue_piece = [&](auto m_c, const int r) {
+        int ring_pos = 0;  // ring slot of input row i
+        // LDS-DMA piece m of one input row.  Everything that depends on the row (scalar offsets of the
+        // two sources, LDS slot) is computed once per row by the caller; a piece this wave does not own
+        // (only the last one can be) is issued all-out-of-range into a sink, so every wave issues exactly
+        // MAXP pieces per row and no branch sits between the MFMAs.
+        auto issue_piece = [&](auto m_c, const unsigned soff0, const unsigned soff1, const unsigned slot_off) {
             constexpr int m = decltype(m_c)::value;
-            if (m < my_pieces) {
-                const int y = y0 - 1 + r;
-                const bool yin = (y >= 0) && (y < H) && (r < nin);
-                const int q = wave + m * C::NWAVES;
-                auto* dst = (__attribute__((address_space(3))) void*)(smem + (r % C::RING) * C::SLOT_BYTES + q * 1024);
-                const bool from_b = psub1[m] && (C::KC == 6);
-                const unsigned soff = yin ? (unsigned)(y * W) * (unsigned)((psub1[m] ? csrc1 : csrc0) * 2) : kOobOffset;
-                if (from_b) lds_dma_b128(rsrc_b, dst, poff[m], soff);
+            const int q = wave + m * C::NWAVES;
+            const bool mine = (m < C::MAXP - 1) || (q < C::NPIECE);
+            const unsigned off = mine ? slot_off + (unsigned)q * 1024u : (unsigned)C::DUMMY_OFF;
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + off);
+            const unsigned soff = (C::NSUB == 2 && psub1[m]) ? soff1 : soff0;
+            if constexpr (C::KC == 6) {
+                if (psub1[m]) lds_dma_b128(rsrc_b, dst, poff[m], soff);
                 else lds_dma_b128(rsrc_a, dst, poff[m], soff);
+            } else {
+                lds_dma_b128(rsrc_a, dst, poff[m], soff);
             }
+        };
+        // scalar row offsets of input row r (kOobOffset: the whole row reads as zeros)
+        auto row_soff = [&](const int r, unsigned& soff0, unsigned& soff1) {
+            const int y = y0 - 1 + r;
+            const bool yin = (y >= 0) & (y < H) & (r < nin);
+            const unsigned pix = (unsigned)(y * W);
+            soff0 = yin ? pix * (unsigned)(csrc0 * 2) : kOobOffset;
+            soff1 = yin ? pix * (unsigned)(csrc1 * 2) : kOobOffset;
         };
 
         // ---- micro-steps of the second epilogue half of output row yy (staging -> HBM), whose
@@ -385,8 +396,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             constexpr int AP = decltype(ap_c)::value;
             constexpr bool TAIL = decltype(tail_c)::value != 0;
             if constexpr (C::HAS_RES) {
-                if (my_pieces == C::MAXP) vm_wait<TAIL ? C::res_wait_tail(C::MAXP) : C::res_wait(C::MAXP)>();
-                else vm_wait<TAIL ? C::res_wait_tail(C::MAXP - 1) : C::res_wait(C::MAXP - 1)>();
+                vm_wait<TAIL ? C::res_wait_tail(C::MAXP) : C::res_wait(C::MAXP)>();
 #pragma unroll
                 for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));  // consumers stay behind the wait
             }
@@ -428,20 +438,26 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             if (i == 0) {
                 vm_wait<0>();
             } else if (i < C::LA - 2) {
-                if (my_pieces == C::MAXP) vm_wait<C::top_wait_early(C::MAXP)>();
-                else vm_wait<C::top_wait_early(C::MAXP - 1)>();
+                vm_wait<C::top_wait_early(C::MAXP)>();
             } else {
-                if (my_pieces == C::MAXP) vm_wait<C::top_wait_steady(C::MAXP)>();
-                else vm_wait<C::top_wait_steady(C::MAXP - 1)>();
+                vm_wait<C::top_wait_steady(C::MAXP)>();
             }
             __builtin_amdgcn_s_barrier();
 
             const int y = y0 + i;
+            // ring slots of input rows i, i+1, i+2 and of the row being fetched (i + LA = slot before i)
+            unsigned dma_s0, dma_s1;
+            row_soff(i + C::LA, dma_s0, dma_s1);
+            const unsigned dma_slot = (unsigned)((ring_pos == 0 ? C::RING - 1 : ring_pos - 1) * C::SLOT_BYTES);
             const unsigned res_soff = (unsigned)y * out_pitch;                       // residual of row i
             const unsigned st_soff = i > 0 ? (unsigned)(y - 1) * out_pitch : kOobOffset;  // stores of row i-1
             unsigned rowa[3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) rowa[ky] = lds_base + ((i + ky) % C::RING) * C::SLOT_BYTES;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sl = ring_pos + ky;
+                rowa[ky] = lds_base + (unsigned)((sl >= C::RING ? sl - C::RING : sl) * C::SLOT_BYTES);
+            }
+            ring_pos = (ring_pos + 1 == C::RING) ? 0 : ring_pos + 1;
 
             if constexpr (PAR == 0) {
                 if (i == 0) {  // first row of the item: nobody fetched its tap 0 yet
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                         constexpr int S = decltype(s_c)::value;
                         if constexpr (t == 0) {
                             if constexpr (S < C::NRES) resv[PAR][S] = buffer_load_b128_async(res_srd, vox[S], res_soff);
-                            else issue_piece(IntC<S - C::NRES>{}, i + C::LA);
+                            else issue_piece(IntC<S - C::NRES>{}, dma_s0, dma_s1, dma_slot);
                         } else if constexpr (t & 1) {
                             constexpr int W0 = (KG == 0 && C::HAS_RES) ? 1 : 0;
                             if constexpr (S < W0) epi_res_wait(IntC<PAR ^ 1>{}, IntC<0>{});
@@ -533,7 +549,12 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous item's rows
 #pragma unroll 1
-        for (int r = 0; r < C::LA; ++r) static_for<0, C::MAXP>([&](auto m_c) { issue_piece(m_c, r); });
+        for (int r = 0; r < C::LA; ++r) {
+            unsigned s0, s1;
+            row_soff(r, s0, s1);
+            static_for<0, C::MAXP>([&](auto m_c) { issue_piece(m_c, s0, s1, (unsigned)(r * C::SLOT_BYTES)); });
+        }
+        ring_pos = 0;
 
 #pragma unroll 1
         for (int i = 0; i < nout; i += 2) {

@@ -22,9 +22,13 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f)
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
 }
+typedef __bf16 srhip_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float srhip_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
 {
-    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    const srhip_f32x2 f = {lo, hi};
+    const srhip_bf16x2 b = __builtin_convertvector(f, srhip_bf16x2);  // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, b);
 }
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
