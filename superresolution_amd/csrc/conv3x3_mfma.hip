@@ -118,6 +118,10 @@ struct Cfg {
     static constexpr int DUMMY_OFF = RING_BYTES + NWAVES * STAGE_BYTES;  // 1 KiB sink of the DMA pieces a wave does not own
     static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
     static constexpr int MPT = KC * NCT;                            // MFMAs per tap
+    // With at least KC + 2 MFMAs per tap the LDS reads of a tap are spread, one per MFMA gap, over the
+    // PREVIOUS tap (gap 0: staging read-back, gaps 1..KC: pixel fragments), and a tap starts with a plain
+    // wait for everything issued at least MPT - KC - 1 MFMAs ago.
+    static constexpr bool SPREAD = MPT >= KC + 2;
     // micro-steps run between the MFMAs of tap t (they belong to the PREVIOUS row's epilogue, except
     // tap 0 which issues this row's residual loads and the LDS-DMA pieces of row i+LA):
     //   tap 0: NRES + MAXP;  tap 2k+1: [residual wait] + channels 0..3 of store group k;
@@ -164,10 +168,16 @@ __device__ __forceinline__ f32x4 lds_read_f32x4(unsigned addr)
     asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
     return r;
 }
-// accumulator quad (AGPRs) straight to LDS: no copy through VGPRs
-__device__ __forceinline__ void lds_write_acc_quad(unsigned addr, const f32x4& q)
+// The accumulator of output tile ct lives in the FIXED registers a[16ct : 16ct+15] (physical-register
+// asm constraints), so that the epilogue can hand any 4-register quad of it to ds_write_b128 by name:
+// no copy through VGPRs and no copy between AGPRs.
+#define SRHIP_ACC_REG0 "{a[0:15]}"
+#define SRHIP_ACC_REG1 "{a[16:31]}"
+template <int CT, int G>
+__device__ __forceinline__ void lds_write_acc_quad(unsigned addr, const f32x16& acc)
 {
-    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "a"(q) : "memory");
+    if constexpr (CT == 0) asm volatile("ds_write_b128 %0, a[%2:%3]" ::"v"(addr), SRHIP_ACC_REG0(acc), "i"(4 * G), "i"(4 * G + 3) : "memory");
+    else asm volatile("ds_write_b128 %0, a[%2:%3]" ::"v"(addr), SRHIP_ACC_REG1(acc), "i"(16 + 4 * G), "i"(16 + 4 * G + 3) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lds_wait()
@@ -178,16 +188,19 @@ __device__ __forceinline__ void lds_wait()
 // One MFMA with the weight fragment pinned to an AGPR (IN_AGPR) or a VGPR.  Written as asm: the
 // builtin lets the register allocator park weights in AGPRs and copy them back (4 moves per MFMA).
 // FIRST: start of an accumulation chain, C = 0 (inline constant), so no accumulator init exists.
-template <bool IN_AGPR, bool FIRST>
+template <bool IN_AGPR, bool FIRST, int CT>
 __device__ __forceinline__ void mfma_pinned(f32x16& acc, const bf16x8& w, const bf16x8& b)
 {
-    if constexpr (IN_AGPR) {
-        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(b));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(b));
-    } else {
-        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "v"(b));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(b));
+#define SRHIP_MFMA_CASE(REG)                                                                                          \
+    if constexpr (IN_AGPR) {                                                                                          \
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=" REG(acc) : "a"(w), "v"(b));   \
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+" REG(acc) : "a"(w), "v"(b));                  \
+    } else {                                                                                                          \
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=" REG(acc) : "v"(w), "v"(b));   \
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+" REG(acc) : "v"(w), "v"(b));                  \
     }
+    if constexpr (CT == 0) { SRHIP_MFMA_CASE(SRHIP_ACC_REG0) } else { SRHIP_MFMA_CASE(SRHIP_ACC_REG1) }
+#undef SRHIP_MFMA_CASE
 }
 
 // Vector-memory operations (LDS-DMA loads, residual loads, output stores) retire in issue order
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
     // residual of row i lives in resv[i & 1]
     u32x4 resv[2][C::NRES > 0 ? C::NRES : 1];
     // epilogue scratch carried between micro-steps
-    f32x4 e_lo, e_hi;
+    f32x4 e_lo[2], e_hi[2];  // staging read-back of store group k lives in buffer k & 1
     float ev[8];
 
     for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
@@ -403,14 +416,14 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
         };
         auto epi_read = [&](auto k_c) {  // staging reads of store group k (complete after the next LDS wait)
             constexpr int k = decltype(k_c)::value;
-            e_lo = lds_read_f32x4(rdst[k]);
-            e_hi = lds_read_f32x4(rdst[k] ^ 16u);
+            e_lo[k & 1] = lds_read_f32x4(rdst[k]);
+            e_hi[k & 1] = lds_read_f32x4(rdst[k] ^ 16u);
         };
         auto epi_elem = [&](auto k_c, auto e_c, auto ap_c) {  // channel e: alpha * act(x + bias) (+ residual)
             constexpr int k = decltype(k_c)::value;
             constexpr int e = decltype(e_c)::value;
             constexpr int AP = decltype(ap_c)::value;
-            const float x = e < 4 ? e_lo[e & 3] : e_hi[e & 3];
+            const float x = e < 4 ? e_lo[k & 1][e & 3] : e_hi[k & 1][e & 3];
             const float t = fmaf(x, p.alpha, breg[e]);
             float v = fmaxf(t, t * p.slope);  // act(t) = max(t, slope * t), slope in {1, 0, s}
             if constexpr (C::HAS_RES) {
@@ -479,17 +492,22 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                 constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;  // its LDS row relative to input row i
                 constexpr int KG = (t - 1) / 2;                  // store group served by taps 2k+1, 2k+2
                 constexpr bool EPI = !C::OUT_F32 && t >= 1 && KG < C::NST;
-                if constexpr (EPI && (t & 1)) epi_read(IntC<KG>{});
-                if (t < 8 || i + 1 < nout) {
-                    static_for<0, C::KC>([&](auto kc_c) {
-                        constexpr int kc = decltype(kc_c)::value;
-                        bq[nxt][kc] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));
-                    });
-                    lds_wait<C::KC>();
-                } else {
+                if constexpr (C::SPREAD) {
                     lds_wait<0>();
+                    if constexpr (EPI && (t & 1)) asm volatile("" : "+v"(e_lo[KG & 1]), "+v"(e_hi[KG & 1]));
+                } else {
+                    if constexpr (EPI && (t & 1)) epi_read(IntC<KG>{});
+                    if (t < 8 || i + 1 < nout) {
+                        static_for<0, C::KC>([&](auto kc_c) {
+                            constexpr int kc = decltype(kc_c)::value;
+                            bq[nxt][kc] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));
+                        });
+                        lds_wait<C::KC>();
+                    } else {
+                        lds_wait<0>();
+                    }
+                    if constexpr (EPI && (t & 1)) asm volatile("" : "+v"(e_lo[KG & 1]), "+v"(e_hi[KG & 1]));  // consumers stay behind the wait
                 }
-                if constexpr (EPI && (t & 1)) asm volatile("" : "+v"(e_lo), "+v"(e_hi));  // consumers stay behind the wait
 
                 constexpr int NS = C::tap_steps(t);
                 static_for<0, C::MPT>([&](auto m_c) {
@@ -497,7 +515,17 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                     constexpr int ml = decltype(m_c)::value;
                     constexpr int kc = ml / C::NCT, ct = ml % C::NCT;
                     constexpr int f = (t * C::KC + kc) * C::NCT + ct;  // MFMA index within the row
-                    mfma_pinned<(f < C::NFA), (t == 0 && kc == 0)>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
+                    mfma_pinned<(f < C::NFA), (t == 0 && kc == 0), ct>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
+                    if constexpr (C::SPREAD) {
+                        // gap 0: staging read-back of the store group the next two taps finish;
+                        // gaps 1..KC: pixel fragments of the next tap
+                        if constexpr (ml == 0 && !C::OUT_F32 && (t % 2 == 0) && (t / 2 < C::NST)) epi_read(IntC<t / 2>{});
+                        if constexpr (ml >= 1 && ml <= C::KC) {
+                            constexpr int kr = ml - 1;
+                            if (t < 8 || i + 1 < nout)
+                                bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kr)]) ^ (unsigned)(C::kcl_of(kr) << 5));
+                        }
+                    }
                     // micro-steps [ml*NS/MPT, (ml+1)*NS/MPT) of this tap
                     static_for<ml * NS / C::MPT, (ml + 1) * NS / C::MPT>([&](auto s_c) {
                         SRHIP_CAPTURE(resv);
@@ -519,8 +547,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             });
 
             // MFMA result -> any other reader: the hazard is invisible to the compiler inside asm
-            if constexpr (C::NCT == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]));
-            else asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]));
+            if constexpr (C::NCT == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]), "+" SRHIP_ACC_REG1(acc[1]));
+            else asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]));
             if constexpr (!C::OUT_F32) {
                 // first epilogue half: accumulator quads (ct, g) = channels 8g+4hl..+3 of pixel pl go
                 // straight from AGPRs to this wave's staging area; the rest of the epilogue runs
@@ -528,8 +556,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                 static_for<0, 4 * C::NCT>([&](auto s_c) {
                     constexpr int S = decltype(s_c)::value;
                     constexpr int ct = S / 4, g = S % 4;
-                    const f32x4 q = __builtin_shufflevector(acc[ct], acc[ct], 4 * g, 4 * g + 1, 4 * g + 2, 4 * g + 3);
-                    lds_write_acc_quad(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), q);
+                    lds_write_acc_quad<ct, g>(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);
                 });
             } else {
                 // fp32 NCHW output (network output / fp32-accumulate checks): plain epilogue.
@@ -570,7 +597,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                 static_for<0, C::NST>([&](auto k_c) {
                     epi_read(k_c);
                     lds_wait<0>();
-                    asm volatile("" : "+v"(e_lo), "+v"(e_hi));
+                    asm volatile("" : "+v"(e_lo[decltype(k_c)::value & 1]), "+v"(e_hi[decltype(k_c)::value & 1]));
                     static_for<0, 8>([&](auto e_c) { epi_elem(k_c, e_c, ap_c); });
                     epi_store(k_c, st_soff);
                 });
