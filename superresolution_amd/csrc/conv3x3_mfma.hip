@@ -96,22 +96,41 @@ struct Cfg {
     static constexpr int STAGE_BYTES = OUT_F32 ? 0 : 32 * PXS;      // per wave
     static constexpr int NSTORE = OUT_F32 ? 16 * NCT : NST;         // store instructions per wave per row
     static constexpr int NRES = HAS_RES ? NST : 0;                  // residual load instructions per wave per row
-    // ---- counted vector-memory waits.  One wave issues per iteration i, in this order:
-    //   [residual loads of row i] [LDS-DMA pieces of row i+LA] [output stores of row i-1]
-    // (fp32 NCHW output: stores of row i).  P = pieces of this wave (MAXP or MAXP-1).
-    // Top of iteration i waits for input row i+2, issued at iteration i+2-LA: younger operations are
-    // that iteration's stores and LA-3 whole iterations.
+    // ---- vector-memory schedule of one row (per wave) and the counted waits that follow from it.
+    // Tap t of iteration i issues, in this order,
+    //   [store of group (t-2)/2 of row i-1: even t >= 2]  [LDS-DMA piece t of row i+LA: t < MAXP]
+    //   [residual load t of row i: t < NRES]
+    // one vector-memory operation of a kind per tap, placed in the late MFMA gaps of the tap (the early
+    // gaps carry the LDS reads).  The fp32 NCHW form appends its 16*NCT stores after tap 8.
     static constexpr int clamp63(int v) { return v > 63 ? 63 : v; }  // vmcnt is a 6-bit field; smaller = safe
-    static constexpr int top_wait_steady(int P) { return clamp63(NSTORE + (LA - 3) * (NRES + P + NSTORE)); }
-    // iterations 1 .. LA-3 of an item: the row was issued by the prologue; row 3's younger operations
-    // at iteration 1 are the fewest and bound all of them.
-    static constexpr int top_wait_early(int P) { return clamp63((LA - 4) * P + NRES + P + NSTORE); }
-    // Residual of row i-1 (loaded in iteration i-1) is consumed in iteration i after the pieces of
-    // iteration i were issued: younger are pieces(i-1), stores(i-2), residual(i), pieces(i).
-    static constexpr int res_wait(int P) { return clamp63(2 * P + NSTORE + NRES); }
-    // ... and after the row loop (last row): younger are that iteration's pieces and stores.
-    static constexpr int res_wait_tail(int P) { return clamp63(P + NSTORE); }
+    static constexpr int store_in_tap(int t) { return (!OUT_F32 && t >= 2 && t % 2 == 0 && (t - 2) / 2 < NST) ? 1 : 0; }
+    static constexpr int dma_in_tap(int t) { return t < MAXP ? 1 : 0; }
+    static constexpr int res_in_tap(int t) { return t < NRES ? 1 : 0; }
+    static constexpr int vm_in_tap(int t) { return store_in_tap(t) + dma_in_tap(t) + res_in_tap(t); }
+    static constexpr int vm_before_tap(int t) { int n = 0; for (int k = 0; k < t; ++k) n += vm_in_tap(k); return n; }
+    static constexpr int VM_ROW = vm_before_tap(9) + (OUT_F32 ? 16 * NCT : 0);  // operations per iteration
+    static constexpr int POS_LAST_DMA = vm_before_tap(MAXP - 1) + store_in_tap(MAXP - 1);
+    static constexpr int POS_LAST_RES = NRES > 0 ? vm_before_tap(NRES - 1) + store_in_tap(NRES - 1) + dma_in_tap(NRES - 1) : 0;
+    // Top of iteration i >= LA-2 waits for input row i+2, issued in iteration i+2-LA: younger are the
+    // rest of that iteration and LA-3 whole iterations.
+    static constexpr int top_wait_steady() { return clamp63((VM_ROW - 1 - POS_LAST_DMA) + (LA - 3) * VM_ROW); }
+    // Iterations 1 .. LA-3: row i+2 came from the prologue; younger are the prologue's later rows and i
+    // whole iterations.  One constant (the smallest) serves them all.
+    static constexpr int top_wait_early() {
+        int best = 1 << 20;
+        for (int i = 1; i <= LA - 3; ++i) {
+            const int n = (LA - 3 - i) * MAXP + i * VM_ROW;
+            if (n < best) best = n;
+        }
+        return clamp63(best);
+    }
+    // The residual of row i-1 is consumed at the first micro-step of tap 1 of iteration i: younger are the
+    // rest of iteration i-1 and tap 0 of iteration i ...
+    static constexpr int res_wait() { return clamp63((VM_ROW - 1 - POS_LAST_RES) + vm_in_tap(0)); }
+    // ... and after the row loop (last row) only the rest of its own iteration.
+    static constexpr int res_wait_tail() { return clamp63(VM_ROW - 1 - POS_LAST_RES); }
     static_assert(LA >= 4, "the wait-count formulas assume at least 4 rows of look-ahead");
+    static_assert(MAXP <= 9 && NRES <= 9, "one LDS-DMA piece and one residual load per tap");
     static constexpr int NFRAG = 9 * KC * NCT;                      // weight fragments per wave
     static constexpr int NFA_MAX = (256 - 16 * NCT) / 4;            // AGPR room beside the accumulators
     static constexpr int NFA = NFRAG < NFA_MAX ? NFRAG : NFA_MAX;   // fragments pinned to AGPRs
@@ -122,17 +141,16 @@ struct Cfg {
     // PREVIOUS tap (gap 0: staging read-back, gaps 1..KC: pixel fragments), and a tap starts with a plain
     // wait for everything issued at least MPT - KC - 1 MFMAs ago.
     static constexpr bool SPREAD = MPT >= KC + 2;
-    // micro-steps run between the MFMAs of tap t (they belong to the PREVIOUS row's epilogue, except
-    // tap 0 which issues this row's residual loads and the LDS-DMA pieces of row i+LA):
-    //   tap 0: NRES + MAXP;  tap 2k+1: [residual wait] + channels 0..3 of store group k;
-    //   tap 2k+2: channels 4..7 + pack/store of group k.
-    static constexpr int tap_steps(int t) {
-        if (t == 0) return NRES + MAXP;
-        if (OUT_F32) return 0;
+    // micro-steps run between the MFMAs of tap t: first the share of the PREVIOUS row's epilogue
+    //   tap 2k+1: [residual wait] + channels 0..3 of store group k;  tap 2k+2: channels 4..7 + pack/store
+    // then this tap's LDS-DMA piece and residual load.
+    static constexpr int epi_steps(int t) {
+        if (t == 0 || OUT_F32) return 0;
         const int k = (t - 1) / 2;
         if (k >= NST) return 0;
         return (t & 1) ? 4 + ((k == 0 && HAS_RES) ? 1 : 0) : 5;
     }
+    static constexpr int tap_steps(int t) { return epi_steps(t) + dma_in_tap(t) + res_in_tap(t); }
 };
 
 // Nested generic lambdas only capture what their own body odr-uses outside discarded branches;
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             constexpr int AP = decltype(ap_c)::value;
             constexpr bool TAIL = decltype(tail_c)::value != 0;
             if constexpr (C::HAS_RES) {
-                vm_wait<TAIL ? C::res_wait_tail(C::MAXP) : C::res_wait(C::MAXP)>();
+                vm_wait<TAIL ? C::res_wait_tail() : C::res_wait()>();
 #pragma unroll
                 for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));  // consumers stay behind the wait
             }
@@ -451,9 +469,9 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             if (i == 0) {
                 vm_wait<0>();
             } else if (i < C::LA - 2) {
-                vm_wait<C::top_wait_early(C::MAXP)>();
+                vm_wait<C::top_wait_early()>();
             } else {
-                vm_wait<C::top_wait_steady(C::MAXP)>();
+                vm_wait<C::top_wait_steady()>();
             }
             __builtin_amdgcn_s_barrier();
 
@@ -530,16 +548,20 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                     static_for<ml * NS / C::MPT, (ml + 1) * NS / C::MPT>([&](auto s_c) {
                         SRHIP_CAPTURE(resv);
                         constexpr int S = decltype(s_c)::value;
-                        if constexpr (t == 0) {
-                            if constexpr (S < C::NRES) resv[PAR][S] = buffer_load_b128_async(res_srd, vox[S], res_soff);
-                            else issue_piece(IntC<S - C::NRES>{}, dma_s0, dma_s1, dma_slot);
-                        } else if constexpr (t & 1) {
-                            constexpr int W0 = (KG == 0 && C::HAS_RES) ? 1 : 0;
-                            if constexpr (S < W0) epi_res_wait(IntC<PAR ^ 1>{}, IntC<0>{});
-                            else epi_elem(IntC<KG>{}, IntC<S - W0>{}, IntC<PAR ^ 1>{});
+                        constexpr int E = C::epi_steps(t);
+                        if constexpr (S < E) {
+                            if constexpr (t & 1) {
+                                constexpr int W0 = (KG == 0 && C::HAS_RES) ? 1 : 0;
+                                if constexpr (S < W0) epi_res_wait(IntC<PAR ^ 1>{}, IntC<0>{});
+                                else epi_elem(IntC<KG>{}, IntC<S - W0>{}, IntC<PAR ^ 1>{});
+                            } else {
+                                if constexpr (S < 4) epi_elem(IntC<KG>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
+                                else epi_store(IntC<KG>{}, st_soff);
+                            }
+                        } else if constexpr (S < E + C::dma_in_tap(t)) {
+                            issue_piece(IntC<t>{}, dma_s0, dma_s1, dma_slot);
                         } else {
-                            if constexpr (S < 4) epi_elem(IntC<KG>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
-                            else epi_store(IntC<KG>{}, st_soff);
+                            resv[PAR][t] = buffer_load_b128_async(res_srd, vox[t], res_soff);
                         }
                     });
                     if constexpr (NS > 0) __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written

@@ -22,7 +22,7 @@ ONLY_64 = [("    SRHIP_CONV_CASE(1, 1, 1)\n    SRHIP_CONV_CASE(2, 1, 1)\n    SRH
 
 NO_BARRIER = [("            __builtin_amdgcn_s_barrier();\n\n            const int y = y0 + i;", "            const int y = y0 + i;")]
 NO_EPI2 = [("constexpr bool EPI = !C::OUT_F32 && t >= 1 && KG < C::NST;", "constexpr bool EPI = false && KG < C::NST;")]
-NO_DMA = [("else issue_piece(IntC<S - C::NRES>{}, dma_s0, dma_s1, dma_slot);", "else { (void)dma_s0; (void)dma_s1; (void)dma_slot; }"),
+NO_DMA = [("                            issue_piece(IntC<t>{}, dma_s0, dma_s1, dma_slot);", "                            (void)dma_s0; (void)dma_s1; (void)dma_slot;"),
           ("            if (i == 0) {\n                vm_wait<0>();\n            } else if (i < C::LA - 2) {", "            if (true) {\n            } else if (i < C::LA - 2) {")]
 NO_FRAG = [("                        bq[nxt][kc] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));", "                        (void)kyn; (void)tn;"),
            ("                    lds_wait<C::KC>();\n                } else {", "                } else {")]
