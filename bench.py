@@ -34,6 +34,9 @@ HR_H, HR_W = LR_H * SCALE, LR_W * SCALE
 FLOP_PER_HR_PX = 2 * 892224
 FLOP_PER_LR_PX = 2 * 19296
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense
+HBM_PEAK_GBS = 8000.0
+# The dominant kernel (64->64 3x3, bf16 NHWC in and out) moves 2 x 128 B per pixel for 73,728 FLOP: 288 FLOP/B,
+# under the machine balance of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, so HBM bandwidth is the roofline that bounds it.
 
 
 def parse():
@@ -94,16 +97,30 @@ def dominant_kernel_time_ms(run_once, hr_h, frames):
     return sum(ts) / len(ts), ts[len(ts) // 2], len(ts)
 
 
+def roofline_block(kernel, flop, nbytes, avg_ms, med_ms, launches, traffic):
+    """Roofline of the dominant kernel from its event-timed average launch duration.  Bound: HBM
+    (arithmetic intensity 288 FLOP/B < 312 FLOP/B machine balance); the MFMA view is kept beside it."""
+    gbs = nbytes / (avg_ms * 1e-3) / 1e9
+    tflops = flop / (avg_ms * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": "bytes/launch (profiles/r1_d_conv64_pmc.csv)" if traffic is not None else None,
+            "avg_launch_ms": avg_ms, "median_launch_ms": med_ms, "launches_timed": launches,
+            "algorithmic_bytes_per_launch": nbytes, "algorithmic_flop_per_launch": flop,
+            "mfma_view": {"achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": tflops / BF16_MFMA_PEAK_TFLOPS}}
+
+
 def measured_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed counter passes (separate
     FETCH_SIZE and WRITE_SIZE runs, KiB units; FETCH_SIZE doubled as gfx950 tallies the 128-byte
     requests of wide streaming reads at 64 bytes).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_b_conv64_pmc.csv")
+    path = os.path.join(ROOT, "profiles", "r1_d_conv64_pmc.csv")
     try:
         vals = {}
         for line in open(path):
             parts = line.rstrip().rsplit(",", 3)
-            if len(parts) == 4 and "Cfg<4, 2, 1, false, false>" in parts[0] and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if len(parts) == 4 and "Cfg<4, 2, 1, false, 0>" in parts[0] and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[parts[1]] = float(parts[3])
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except (OSError, KeyError, ValueError):
@@ -214,7 +231,6 @@ def run_train(args, world, rank, dev, dist):
     flop_step = 3 * fwd - no_dgrad
     k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, S, 2)
     k_flop = 2.0 * B * S * S * 64 * 64 * 9
-    achieved = k_flop / (k_avg_ms * 1e-3) / 1e12
     res = {
         "metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs",
         "value": world * B * args.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
@@ -226,13 +242,9 @@ def run_train(args, world, rank, dev, dist):
                    "crops_per_step_per_gpu": B, "tflop_per_step_per_gpu": flop_step / 1e12,
                    "net_tflops_per_gpu": flop_step / 1e12 / (ms_per_step * 1e-3),
                    "net_frac_of_bf16_mfma_peak": flop_step / 1e12 / (ms_per_step * 1e-3) / BF16_MFMA_PEAK_TFLOPS},
-        "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<Cfg<4,2,1,false,0>> (64->64 3x3 + bias + ReLU @ {B}x{S}x{S}; "
-                                                 "the same kernel runs every data gradient)",
-                     "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "avg_launch_ms": k_avg_ms, "median_launch_ms": k_med_ms, "launches_timed": k_launches,
-                     "algorithmic_flop_per_launch": k_flop,
-                     "algorithmic_bytes_per_launch": 2.0 * B * S * S * 64 * 2},
+        "roofline": roofline_block(f"conv3x3_kernel<Cfg<4,2,1,false,0>> (64->64 3x3 + bias + ReLU @ {B}x{S}x{S}; the same kernel "
+                                   "runs every data gradient)", k_flop, 2.0 * B * S * S * 64 * 2, k_avg_ms, k_med_ms,
+                                   k_launches, None),
     }
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_train(args.cpu_train_crop)
@@ -289,7 +301,6 @@ def main():
         flop_frame = FLOP_PER_HR_PX * HR_H * HR_W + FLOP_PER_LR_PX * LR_H * LR_W
         k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, HR_H, 5)
         k_flop = 2.0 * HR_H * HR_W * 64 * 64 * 9
-        achieved = k_flop / (k_avg_ms * 1e-3) / 1e12
         res = {
             "metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -300,13 +311,9 @@ def main():
                        "tflop_per_frame": flop_frame / 1e12,
                        "net_tflops": flop_frame / 1e12 / (ms_per_step * 1e-3),
                        "net_frac_of_bf16_mfma_peak": flop_frame / 1e12 / (ms_per_step * 1e-3) / BF16_MFMA_PEAK_TFLOPS},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel<Cfg<4,2,1,false,false>> (64->64 3x3 + bias + ReLU @ 2160x3840, 12 of the 25 HR launches per frame)",
-                         "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": measured_traffic_bytes(),
-                         "traffic_unit": "bytes/launch (profiles/r1_b_conv64_pmc.csv)",
-                         "avg_launch_ms": k_avg_ms, "median_launch_ms": k_med_ms, "launches_timed": k_launches,
-                         "algorithmic_flop_per_launch": k_flop,
-                         "algorithmic_bytes_per_launch": 2.0 * HR_H * HR_W * 64 * 2},
+            "roofline": roofline_block("conv3x3_kernel<Cfg<4,2,1,false,0>> (64->64 3x3 + bias + ReLU @ 2160x3840, "
+                                       "12 of the 25 HR launches per frame)", k_flop, 2.0 * HR_H * HR_W * 64 * 2,
+                                       k_avg_ms, k_med_ms, k_launches, measured_traffic_bytes()),
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_crop)

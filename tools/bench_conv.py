@@ -41,6 +41,10 @@ if __name__ == "__main__":
         case("64->64 relu", 64, 0, 64)
         case("64->64 relu 16x1024^2", 64, 0, 64, h=1024, w=1024, n=16)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bands":
+        for hh in (2160, 1080, 540, 360, 216, 108, 54, 27):
+            case(f"64->64 relu h={hh}", 64, 0, 64, h=hh)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "quick":
         case("64->64 relu", 64, 0, 64)
         case("16->64 relu", 16, 0, 64)
@@ -68,7 +72,7 @@ def wgrad_case(name, ci, co, h=1024, w=1024, n=16):
     print(f"wgrad {name:22s} median {med:7.3f} ms  best {best:7.3f} ms  {flop / med / 1e9:8.1f} TFLOP/s  {byts / med / 1e6:7.1f} GB/s", flush=True)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("quick", "one")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("quick", "one", "bands")):
     wgrad_case("64x64 16x1024^2", 64, 64)
     wgrad_case("32x64 16x1024^2", 32, 64)
     wgrad_case("16x64 16x1024^2", 16, 64)

@@ -24,8 +24,15 @@ NO_BARRIER = [("            __builtin_amdgcn_s_barrier();\n\n            const i
 NO_EPI2 = [("constexpr bool EPI = !C::OUT_F32 && t >= 1 && KG < C::NST;", "constexpr bool EPI = false && KG < C::NST;")]
 NO_DMA = [("                            issue_piece(IntC<t>{}, dma_s0, dma_s1, dma_slot);", "                            (void)dma_s0; (void)dma_s1; (void)dma_slot;"),
           ("            if (i == 0) {\n                vm_wait<0>();\n            } else if (i < C::LA - 2) {", "            if (true) {\n            } else if (i < C::LA - 2) {")]
+DMA_CACHED = [("            soff0 = yin ? pix * (unsigned)(csrc0 * 2) : kOobOffset;", "            soff0 = yin ? (pix & 0xfffu) * (unsigned)(csrc0 * 2) : kOobOffset;")]
+NO_STORE = [("            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);", "            if (store_soff == 12345u) __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);")]
+NT_STORE = [("            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);", "            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 2);")]
+NT_LOAD = [("    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 0);", "    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 2);")]
+SC_STORE = [("            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);", "            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 17);")]
+LA6 = [("    static constexpr int LA = 5;", "    static constexpr int LA = 6;")]
+LA4 = [("    static constexpr int LA = 5;", "    static constexpr int LA = 4;")]
 NO_FRAG = [("                        bq[nxt][kc] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));", "                        (void)kyn; (void)tn;"),
-           ("                    lds_wait<C::KC>();\n                } else {", "                } else {")]
+           ("                                bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kr)]) ^ (unsigned)(C::kcl_of(kr) << 5));", "                                (void)kr;")]
 NO_EPI1 = [("                    lds_write_acc_quad<ct, g>(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);", "                    (void)wst;")]
 NO_NOP = [('asm volatile("s_nop 15\\n\\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]), "+" SRHIP_ACC_REG1(acc[1]));', 'asm volatile("" : "+" SRHIP_ACC_REG0(acc[0]), "+" SRHIP_ACC_REG1(acc[1]));')]
 
@@ -34,6 +41,16 @@ VARIANTS = {
     "nobarrier": NO_BARRIER,
     "noepi2": NO_EPI2,
     "nodma": NO_DMA,
+    "dmacached": DMA_CACHED,
+    "nostore": NO_STORE,
+    "la6": LA6,
+    "la4": LA4,
+    "la6nt": LA6 + NT_STORE + NT_LOAD,
+    "ntstore": NT_STORE,
+    "ntload": NT_LOAD,
+    "ntboth": NT_STORE + NT_LOAD,
+    "scstore": SC_STORE,
+    "nostore_dmacached": NO_STORE + DMA_CACHED,
     "nofrag": NO_FRAG,
     "noepi": NO_EPI2 + NO_EPI1 + NO_NOP,
     "mfmaonly": NO_BARRIER + NO_EPI2 + NO_DMA + NO_FRAG + NO_EPI1 + NO_NOP,
@@ -55,7 +72,10 @@ def build():
     base = open(os.path.join(SRC, "conv3x3_mfma.hip")).read()
     objs = [os.path.join(ROOT, "build", "obj", o) for o in ("runtime.o", "conv3x3_wgrad.o", "conv_direct.o", "memops.o", "loss.o")]
     procs = []
+    only = sys.argv[2:]
     for name, subs in VARIANTS.items():
+        if only and name not in only:
+            continue
         src = os.path.join(BUILD, f"conv_{name}.hip")
         text = patch(base, ONLY_64 + subs, name).replace('#include "srhip_common.h"', f'#include "{SRC}/srhip_common.h"')
         open(src, "w").write(text)
@@ -75,6 +95,6 @@ def build():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "list":
-        print(" ".join(VARIANTS))
+        print(" ".join(v for v in VARIANTS if os.path.exists(os.path.join(OUT, f"libsrhip_{v}.so"))))
     else:
         build()
