@@ -137,6 +137,18 @@ SRHIP_API int srhip_conv2d_direct(const void* src, const float* w, const float* 
                                   int cout_stride, int kh, int kw, int sh, int sw, int ph, int pw,
                                   int act, float slope, float alpha, void* stream);
 
+/* nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2) (+ReLU), TransConvActivation of
+ * core/models/model_final.py:198-203.  src (N,h,w,cin_stride) bf16 -> dst (N,2h,2w,cout_stride) bf16;
+ * w is the fp32 (cin, cout, 2, 2) weight of the module (device); act: none or ReLU. */
+SRHIP_API int srhip_conv_transpose2x2s2(const void* src, const float* w, const float* bias, void* dst, int n,
+                                        int h, int wd, int cin, int cin_stride, int cout, int cout_stride,
+                                        int act, void* stream);
+
+/* GradientMap of core/models/model_final.py:160-187 on fp32 (planes, h, w):
+ * sqrt(gv^2 + gh^2 + eps) of the fixed vertical / horizontal 3x3 difference stencils, zero padding. */
+SRHIP_API int srhip_gradient_map_f32(const float* src, float* dst, int planes, int h, int w, float eps,
+                                     void* stream);
+
 /* ---------------------------------------------------------------------------
  * Memory-bound operators.
  * ------------------------------------------------------------------------- */
@@ -170,13 +182,15 @@ SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t cou
 
 /* ESA attention helpers of RepRFN (core/arch/RepRFN.py:295-308) on NHWC bf16, c % 8 == 0:
  *   max_pool2d:      F.max_pool2d(x, kernel_size=k, stride=s)  (no padding)       :298
- *   resize_bilinear: F.interpolate(x, (ho,wo), mode="bilinear", align_corners=False) + addend
+ *   resize_bilinear: F.interpolate(x, (ho,wo), mode="bilinear", align_corners) + addend
  *                    (addend (N,ho,wo,c) or NULL; the reference adds conv_f(c1_))  :303,305
+ *                    align_corners = 1 is nn.Upsample(x2, bilinear, align_corners=True) of
+ *                    core/models/model_final.py:281-289
  *   sigmoid_gate:    dst = x * sigmoid(gate)                                       :306-308 */
 SRHIP_API int srhip_max_pool2d_nhwc(const void* src, void* dst, int n, int c, int h, int w, int k, int s,
                                     void* stream);
 SRHIP_API int srhip_resize_bilinear_nhwc(const void* src, const void* addend, void* dst, int n, int c,
-                                         int h, int w, int ho, int wo, void* stream);
+                                         int h, int w, int ho, int wo, int align_corners, void* stream);
 SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst, size_t count, void* stream);
 
 /* Fused loss of the default trainer configuration, forward AND backward in one call:

@@ -465,4 +465,69 @@ ORC_API void orc_resize_bilinear(const float* in, float* out, int NC, int H, int
         }
 }
 
+/* nn.ConvTranspose2d(kernel 2, stride 2, padding 0), core/models/model_final.py:198-203:
+   out[n][co][2y+i][2x+j] = b[co] + sum_ci in[n][ci][y][x] * w[ci][co][i][j]   (w: (Cin, Cout, 2, 2)) */
+ORC_API void orc_conv_transpose2x2s2(const float* in, const float* w, const float* b, float* out, int N, int Cin,
+                                     int H, int W, int Cout, int relu)
+{
+    const int Ho = 2 * H, Wo = 2 * W;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int co = 0; co < Cout; ++co)
+            for (int oy = 0; oy < Ho; ++oy)
+                for (int ox = 0; ox < Wo; ++ox) {
+                    const int y = oy >> 1, i = oy & 1, x = ox >> 1, j = ox & 1;
+                    float acc = b ? b[co] : 0.0f;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        acc += in[(((size_t)n * Cin + ci) * H + y) * W + x] * w[(((size_t)ci * Cout + co) * 2 + i) * 2 + j];
+                    if (relu && acc < 0.0f) acc = 0.0f;
+                    out[(((size_t)n * Cout + co) * Ho + oy) * Wo + ox] = acc;
+                }
+}
+
+/* F.interpolate / nn.Upsample(mode="bilinear", align_corners=True): src = dst * (in-1)/(out-1)
+   (core/models/model_final.py:281-289). */
+ORC_API void orc_resize_bilinear_ac(const float* in, float* out, int NC, int H, int W, int Ho, int Wo)
+{
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.0f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.0f;
+    for (int p = 0; p < NC; ++p)
+        for (int oy = 0; oy < Ho; ++oy) {
+            const float fy = sy * (float)oy;
+            const int y0 = (int)fy;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, hy = 1.0f - ly;
+            for (int ox = 0; ox < Wo; ++ox) {
+                const float fx = sx * (float)ox;
+                const int x0 = (int)fx;
+                const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+                const float lx = fx - (float)x0, hx = 1.0f - lx;
+                const float* ip = in + (size_t)p * H * W;
+                out[((size_t)p * Ho + oy) * Wo + ox] =
+                    hy * (hx * ip[(size_t)y0 * W + x0] + lx * ip[(size_t)y0 * W + x1]) +
+                    ly * (hx * ip[(size_t)y1 * W + x0] + lx * ip[(size_t)y1 * W + x1]);
+            }
+        }
+}
+
+/* GradientMap, core/models/model_final.py:160-187: sqrt(gv^2 + gh^2 + eps) of the fixed 3x3 stencils
+   kernel_v = [[-1,-1,-1],[0,0,0],[1,1,1]], kernel_h = [[-1,0,1],[-1,0,1],[-1,0,1]], zero padding. */
+ORC_API void orc_gradient_map(const float* in, float* out, int NC, int H, int W, float eps)
+{
+    for (int p = 0; p < NC; ++p)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float gv = 0.0f, gh = 0.0f;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int yy = y + ky - 1, xx = x + kx - 1;
+                        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                        const float v = in[((size_t)p * H + yy) * W + xx];
+                        gv += (float)(ky - 1) * v;
+                        gh += (float)(kx - 1) * v;
+                    }
+                out[((size_t)p * H + y) * W + x] = sqrtf(gv * gv + gh * gh + eps);
+            }
+}
+
 ORC_API int orc_version(void) { return 1; }

@@ -208,6 +208,33 @@ def resize_bilinear(x, Ho, Wo):
     return out
 
 
+def conv_transpose2x2s2(x, w, b=None, relu=False):
+    """nn.ConvTranspose2d(Cin, Cout, 2, 2) (+ReLU), w (Cin, Cout, 2, 2)."""
+    x, w = _c(x), _c(w)
+    b = _c(b) if b is not None else None
+    N, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    out = np.empty((N, Cout, 2 * H, 2 * W), np.float32)
+    lib().orc_conv_transpose2x2s2(_p(x), _p(w), _p(b), _p(out), _i(N), _i(Cin), _i(H), _i(W), _i(Cout), _i(int(relu)))
+    return out
+
+
+def resize_bilinear_align_corners(x, Ho, Wo):
+    x = _c(x)
+    N, C, H, W = x.shape
+    out = np.empty((N, C, Ho, Wo), np.float32)
+    lib().orc_resize_bilinear_ac(_p(x), _p(out), _i(N * C), _i(H), _i(W), _i(Ho), _i(Wo))
+    return out
+
+
+def gradient_map(x, eps=1e-6):
+    x = _c(x)
+    N, C, H, W = x.shape
+    out = np.empty_like(x)
+    lib().orc_gradient_map(_p(x), _p(out), _i(N * C), _i(H), _i(W), ctypes.c_float(eps))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # model-level restatements
 # ---------------------------------------------------------------------------

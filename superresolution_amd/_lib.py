@@ -66,7 +66,9 @@ _SIGNATURES = {
     "srhip_relu_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "srhip_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "srhip_max_pool2d_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
-    "srhip_resize_bilinear_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_resize_bilinear_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "srhip_conv_transpose2x2s2": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
+    "srhip_gradient_map_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "srhip_sigmoid_gate_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "srhip_l1_ssim_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_l1_ssim_loss": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 4 + [c_void_p]),

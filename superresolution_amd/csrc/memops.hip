@@ -83,6 +83,25 @@ __global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ src, unsi
     }
 }
 
+// any channel count: one thread = one pixel x 8 channels
+__global__ void nchw_f32_to_nhwc_bf16_generic_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                     int n, int c, long long hw, int cpad)
+{
+    const int cg = cpad / 8;
+    const long long total = (long long)n * hw * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i % ((long long)n * hw);  // pixel fastest: coalesced reads of each channel plane
+        const int g = (int)(i / ((long long)n * hw));
+        const long long img = p / hw, pix = p - img * hw;
+        const float* sp = src + img * c * hw + pix;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (g * 8 + k < c) ? sp[(long long)(g * 8 + k) * hw] : 0.0f;
+        *(uint4*)(dst + p * cpad + g * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                       pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+}
+
 __global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst,
                                              int n, int c, long long hw, int cstride)
 {
@@ -266,21 +285,22 @@ __global__ void max_pool_nhwc_kernel(const unsigned short* __restrict__ src, uns
         *(uint4*)(dst + (((long long)img * ho + oy) * wo + ox) * c + g * 8) = pack8(m);
     }
 }
-// F.interpolate(size=(ho,wo), mode="bilinear", align_corners=False) (+ optional addend of the output shape)
+// F.interpolate / nn.Upsample(size=(ho,wo), mode="bilinear", align_corners=align) (+ optional addend of the output shape)
 __global__ void resize_bilinear_nhwc_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ addend,
-                                            unsigned short* __restrict__ dst, int n, int c, int h, int w, int ho, int wo)
+                                            unsigned short* __restrict__ dst, int n, int c, int h, int w, int ho, int wo, int align)
 {
     const int cg = c / 8;
     const long long total = (long long)n * ho * wo * cg;
-    const float sy = (float)h / (float)ho, sx = (float)w / (float)wo;
+    const float sy = align ? (ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.0f) : (float)h / (float)ho;
+    const float sx = align ? (wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.0f) : (float)w / (float)wo;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
         long long p = i / cg;
         const int ox = (int)(p % wo); p /= wo;
         const int oy = (int)(p % ho);
         const int img = (int)(p / ho);
-        float fy = __fsub_rn(__fmul_rn(sy, (float)oy + 0.5f), 0.5f);
-        float fx = __fsub_rn(__fmul_rn(sx, (float)ox + 0.5f), 0.5f);
+        float fy = align ? __fmul_rn(sy, (float)oy) : __fsub_rn(__fmul_rn(sy, (float)oy + 0.5f), 0.5f);
+        float fx = align ? __fmul_rn(sx, (float)ox) : __fsub_rn(__fmul_rn(sx, (float)ox + 0.5f), 0.5f);
         if (fy < 0.0f) fy = 0.0f;
         if (fx < 0.0f) fx = 0.0f;
         const int y0 = (int)fy, x0 = (int)fx;
@@ -315,6 +335,31 @@ __global__ void sigmoid_gate_kernel(const uint4* __restrict__ x, const uint4* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = a[e] * (1.0f / (1.0f + expf(-b[e])));
         dst[i] = pack8(a);
+    }
+}
+
+// GradientMap (core/models/model_final.py:160-187) on fp32 planes: sqrt(gv^2 + gh^2 + eps) with the fixed
+// stencils kernel_v = rows (-1, 0, +1), kernel_h = columns (-1, 0, +1), zero padding.
+__global__ void gradient_map_kernel(const float* __restrict__ src, float* __restrict__ dst, long long planes, int h, int w,
+                                    float eps)
+{
+    const long long total = planes * h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        const float* pl = src + (i / ((long long)h * w)) * h * w;
+        float gv = 0.0f, gh = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                const float v = pl[(long long)yy * w + xx];
+                gv += (float)(ky - 1) * v;
+                gh += (float)(kx - 1) * v;
+            }
+        dst[i] = sqrtf(gv * gv + gh * gh + eps);
     }
 }
 
@@ -584,7 +629,11 @@ SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, in
         case 32: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<32>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
         case 48: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<48>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
         case 64: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<64>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
-        default: srhip_set_error("nchw_f32_to_nhwc_bf16: cpad must be 16, 32, 48 or 64 (got %d)", cpad); return SRHIP_ERR_INVALID;
+        default:
+            SRHIP_REQUIRE(cpad % 8 == 0, "nchw_f32_to_nhwc_bf16: cpad must be a multiple of 8 (got %d)", cpad);
+            hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_generic_kernel, dim3(grid_for((long long)n * hw * (cpad / 8), srhip_num_cus())),
+                               dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw, cpad);
+            break;
     }
     return srhip_check_launch("nchw_f32_to_nhwc_bf16");
 }
@@ -792,13 +841,13 @@ SRHIP_API int srhip_max_pool2d_nhwc(const void* src, void* dst, int n, int c, in
 }
 
 SRHIP_API int srhip_resize_bilinear_nhwc(const void* src, const void* addend, void* dst, int n, int c, int h, int w, int ho,
-                                         int wo, void* stream)
+                                         int wo, int align_corners, void* stream)
 {
     SRHIP_REQUIRE(src && dst, "resize_bilinear_nhwc: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && h >= 1 && w >= 1 && ho >= 1 && wo >= 1, "resize_bilinear_nhwc: bad shape (c %% 8 == 0)");
     const long long work = (long long)n * ho * wo * (c / 8);
     hipLaunchKernelGGL(resize_bilinear_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const unsigned short*)src, (const unsigned short*)addend, (unsigned short*)dst, n, c, h, w, ho, wo);
+                       (const unsigned short*)src, (const unsigned short*)addend, (unsigned short*)dst, n, c, h, w, ho, wo, align_corners);
     return srhip_check_launch("resize_bilinear_nhwc");
 }
 
@@ -811,6 +860,15 @@ SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst
     hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4*)x, (const uint4*)gate, (uint4*)dst, nvec);
     return srhip_check_launch("sigmoid_gate_bf16");
+}
+
+SRHIP_API int srhip_gradient_map_f32(const float* src, float* dst, int planes, int h, int w, float eps, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "gradient_map_f32: null pointer");
+    SRHIP_REQUIRE(planes >= 1 && h >= 1 && w >= 1, "gradient_map_f32: bad shape");
+    hipLaunchKernelGGL(gradient_map_kernel, dim3(grid_for((long long)planes * h * w, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, src, dst, (long long)planes, h, w, eps);
+    return srhip_check_launch("gradient_map_f32");
 }
 
 SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t pixels, int ca, int cb, void* stream)

@@ -179,6 +179,53 @@ def upsample_grid_bilinear_bwd_nhwc(dy: torch.Tensor, sh: int, sw: int, relu_out
     return out
 
 
+def conv_transpose2x2s2(src: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], cin: int, act: int = ACT_NONE,
+                        cout_stride: Optional[int] = None) -> torch.Tensor:
+    """nn.ConvTranspose2d(cin, cout, 2, 2) (+ReLU) on NHWC bf16; weight is the module's fp32 (cin, cout, 2, 2) tensor."""
+    src = _req(src, torch.bfloat16, "src")
+    weight = _req(weight, torch.float32, "weight")
+    n, h, w, cs = src.shape
+    if weight.dim() != 4 or weight.shape[0] != cin or tuple(weight.shape[2:]) != (2, 2):
+        raise ValueError("conv_transpose2x2s2: weight must be (cin, cout, 2, 2)")
+    cout = weight.shape[1]
+    cout_stride = pad16(cout) if cout_stride is None else cout_stride
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias")
+    out = torch.empty((n, 2 * h, 2 * w, cout_stride), dtype=torch.bfloat16, device=src.device)
+    check(lib.srhip_conv_transpose2x2s2(src.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), n, h, w, cin, cs, cout,
+                                        cout_stride, act, _stream()))
+    return out
+
+
+def gradient_map(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """GradientMap (core/models/model_final.py:160-187) on an fp32 (N,C,H,W) tensor."""
+    x = _req(x, torch.float32, "x")
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    check(lib.srhip_gradient_map_f32(x.data_ptr(), out.data_ptr(), n * c, h, w, eps, _stream()))
+    return out
+
+
+def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 1,
+                act: int = ACT_NONE, slope: float = 0.0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Conv2d (+activation, +residual) on an NHWC bf16 tensor with any channel count: the 3x3 / stride 1 /
+    pad 1 layers whose input fits one MFMA source (<= 64 padded channels) run on the MFMA kernel, in slices of
+    64 output channels; everything else (1x1, strided, wider inputs) runs on the direct kernel.
+    x carries pad16(cin) channels; the result carries pad16(cout)."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw, stride, padding) == (3, 3, 1, 1) and x.shape[-1] <= 64 and (cout <= 64 or cout % 64 == 0) and (res is None or cout <= 64):
+        if cout <= 64:
+            wp = conv3x3_pack_weights(weight, cin, x.shape[-1])
+            return conv3x3(x, wp, bias, cout, res=res, act=act, slope=slope)
+        out = None
+        for off in range(0, cout, 64):
+            wp = conv3x3_pack_weights(weight, cin, x.shape[-1], cout=64, cout_off=off)
+            part = conv3x3(x, wp, None if bias is None else bias[off:off + 64].contiguous(), 64, act=act, slope=slope)
+            out = part if out is None else concat_nhwc(out, part)
+        return out
+    return conv2d_direct(x, weight, bias, cin, stride=stride, padding=padding, res=res, act=act, slope=slope)
+
+
 def max_pool2d_nhwc(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
     x = _req(x, torch.bfloat16, "x")
     n, h, w, c = x.shape
@@ -187,8 +234,9 @@ def max_pool2d_nhwc(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
     return out
 
 
-def resize_bilinear_nhwc(x: torch.Tensor, ho: int, wo: int, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """F.interpolate(x, (ho, wo), mode="bilinear", align_corners=False) (+ addend) on NHWC bf16."""
+def resize_bilinear_nhwc(x: torch.Tensor, ho: int, wo: int, addend: Optional[torch.Tensor] = None,
+                         align_corners: bool = False) -> torch.Tensor:
+    """F.interpolate(x, (ho, wo), mode="bilinear", align_corners=align_corners) (+ addend) on NHWC bf16."""
     x = _req(x, torch.bfloat16, "x")
     n, h, w, c = x.shape
     if addend is not None:
@@ -196,7 +244,7 @@ def resize_bilinear_nhwc(x: torch.Tensor, ho: int, wo: int, addend: Optional[tor
         if tuple(addend.shape) != (n, ho, wo, c):
             raise ValueError("resize_bilinear_nhwc: addend must have the output shape")
     out = torch.empty((n, ho, wo, c), dtype=torch.bfloat16, device=x.device)
-    check(lib.srhip_resize_bilinear_nhwc(x.data_ptr(), _ptr(addend), out.data_ptr(), n, c, h, w, ho, wo, _stream()))
+    check(lib.srhip_resize_bilinear_nhwc(x.data_ptr(), _ptr(addend), out.data_ptr(), n, c, h, w, ho, wo, int(align_corners), _stream()))
     return out
 
 

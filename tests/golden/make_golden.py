@@ -304,13 +304,54 @@ def gen_reprfn_init():
     print("reprfn_init.npz:", len(out["train.keys"]), "train keys,", len(out["deploy.keys"]), "deploy keys")
 
 
+def gen_temporal_ops():
+    """Operators of the temporal variant (core/models/model_final.py) at small shapes, run on the
+    reference's own module classes: GradientMap, TransConvActivation, ConvActivation (1x1, stride 2),
+    nn.Upsample(x2, bilinear, align_corners=True)."""
+    torch.cuda.current_device = lambda: "cpu"   # core/tools/color.py builds constants on "the current device"
+    from core.models.model_final import ConvActivation, GradientMap, TransConvActivation
+    g = torch.Generator().manual_seed(23)
+    out = {}
+    x = rnd(g, 2, 6, 13, 18, lo=0.0, hi=1.0)
+    out["grad.x"] = x.numpy(); out["grad.y"] = GradientMap(6)(x).numpy()
+    torch.manual_seed(5)
+    for name, (ci, co) in {"t64_64": (64, 64), "t192_192": (192, 192)}.items():
+        m = TransConvActivation(ci, co, 2, 2)
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.copy_(bf16_round(p_ if p_.dim() > 1 else torch.randn(p_.shape, generator=g) * 0.05))
+        xi = bf16_round(rnd(g, 1, ci, 5, 7))
+        out[f"convT.{name}.x"] = xi.numpy(); out[f"convT.{name}.w"] = m[0].weight.detach().numpy()
+        out[f"convT.{name}.b"] = m[0].bias.detach().numpy(); out[f"convT.{name}.y"] = m(xi).detach().numpy()
+    for name, (ci, co, k, st, pd) in {"s2_32_48": (32, 48, 3, 2, 1), "s2_192_256": (192, 256, 3, 2, 1),
+                                        "p1_160_160": (160, 160, 1, 1, 0), "p1_112_64": (112, 64, 1, 1, 0),
+                                        "c3_160_128": (160, 128, 3, 1, 1), "c3_24_64": (24, 64, 3, 1, 1)}.items():
+        m = ConvActivation(ci, co, k, st, pd)
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.copy_(bf16_round(p_ if p_.dim() > 1 else torch.randn(p_.shape, generator=g) * 0.05))
+        xi = bf16_round(rnd(g, 1, ci, 9, 12))
+        out[f"tconv.{name}.x"] = xi.numpy(); out[f"tconv.{name}.w"] = m[0].weight.detach().numpy()
+        out[f"tconv.{name}.b"] = m[0].bias.detach().numpy(); out[f"tconv.{name}.y"] = m(xi).detach().numpy()
+        out[f"tconv.{name}.geom"] = np.array([k, st, pd], np.int64)
+    up = torch.nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+    xu = bf16_round(rnd(g, 2, 16, 5, 9))
+    out["up2.x"] = xu.numpy(); out["up2.y"] = up(xu).numpy()
+    np.savez_compressed(os.path.join(OUT, "temporal_ops.npz"), **out)
+    print("temporal_ops.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     _stub_modules()
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "reprfn_init":
         gen_reprfn_init()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "temporal_ops":
+        gen_temporal_ops()
+        sys.exit(0)
     gen_ops()
     gen_supersampler()
     gen_reprfn()
     gen_reprfn_init()
+    gen_temporal_ops()

@@ -1,0 +1,81 @@
+"""GPU parity of the temporal variant's operators (core/models/model_final.py): transposed 2x2/stride-2
+convolution, x2 bilinear up-sampling with align_corners=True, GradientMap, and its convolution shapes
+(1x1, 3x3 stride 2, wide 3x3) through the auto-dispatching convolution, against outputs of the reference's
+own modules (tests/golden/temporal_ops.npz) and the CPU oracle.  bf16 outputs: <= 2e-2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F_():
+    from superresolution_amd import functional
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return functional
+
+
+@pytest.fixture(scope="module")
+def z():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "temporal_ops.npz"))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_gradient_map_golden(F_, z):
+    y = F_.gradient_map(dev(z["grad.x"])).cpu().numpy()
+    assert np.abs(y - z["grad.y"]).max() <= 2e-6
+    rng = np.random.default_rng(1)
+    x = rng.random((3, 6, 40, 57), dtype=np.float32)
+    assert np.abs(F_.gradient_map(dev(x)).cpu().numpy() - orc.gradient_map(x)).max() <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["t64_64", "t192_192"])
+def test_conv_transpose_golden(F_, z, name):
+    x, w, b = z[f"convT.{name}.x"], z[f"convT.{name}.w"], z[f"convT.{name}.b"]
+    y = F_.conv_transpose2x2s2(F_.nchw_f32_to_nhwc_bf16(dev(x)), dev(w), dev(b), x.shape[1], act=F_.ACT_RELU)
+    got = F_.nhwc_bf16_to_nchw_f32(y, w.shape[1]).cpu().numpy()
+    assert got.shape == z[f"convT.{name}.y"].shape
+    assert np.abs(got - z[f"convT.{name}.y"]).max() <= 2e-2
+    assert np.abs(got - orc.conv_transpose2x2s2(x, w, b, relu=True)).max() <= 2e-2
+
+
+@pytest.mark.parametrize("name", ["s2_32_48", "s2_192_256", "p1_160_160", "p1_112_64", "c3_160_128", "c3_24_64"])
+def test_temporal_conv_shapes_golden(F_, z, name):
+    key = "tconv." + name
+    k, st, pd = (int(v) for v in z[key + ".geom"])
+    x, w, b = z[key + ".x"], z[key + ".w"], z[key + ".b"]
+    y = F_.conv2d_auto(F_.nchw_f32_to_nhwc_bf16(dev(x)), dev(w), dev(b), stride=st, padding=pd, act=F_.ACT_RELU)
+    got = F_.nhwc_bf16_to_nchw_f32(y, w.shape[0]).cpu().numpy()
+    assert got.shape == z[key + ".y"].shape
+    assert np.abs(got - z[key + ".y"]).max() <= 2e-2
+
+
+def test_conv2d_auto_wide_output_uses_mfma_slices(F_):
+    """3x3 with 64 inputs and 128 outputs: two MFMA launches over cout_off, against the oracle."""
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.standard_normal((1, 64, 20, 33)).astype(np.float32)).to(torch.bfloat16).float().numpy()
+    w = torch.from_numpy((rng.standard_normal((128, 64, 3, 3)) * 0.05).astype(np.float32)).to(torch.bfloat16).float().numpy()
+    b = (rng.standard_normal(128) * 0.1).astype(np.float32)
+    y = F_.conv2d_auto(F_.nchw_f32_to_nhwc_bf16(dev(x)), dev(w), dev(b), act=F_.ACT_RELU)
+    assert y.shape == (1, 20, 33, 128)
+    got = F_.nhwc_bf16_to_nchw_f32(y, 128).cpu().numpy()
+    assert np.abs(got - orc.conv2d(x, w, b, 1, 1, act=1)).max() <= 2e-2
+
+
+def test_upsample_x2_align_corners_golden(F_, z):
+    x = z["up2.x"]
+    y = F_.resize_bilinear_nhwc(F_.nchw_f32_to_nhwc_bf16(dev(x)), 2 * x.shape[2], 2 * x.shape[3], align_corners=True)
+    got = F_.nhwc_bf16_to_nchw_f32(y, x.shape[1]).cpu().numpy()
+    assert np.abs(got - z["up2.y"]).max() <= 1e-2
+    rng = np.random.default_rng(3)
+    x2 = torch.from_numpy(rng.standard_normal((1, 32, 7, 11)).astype(np.float32)).to(torch.bfloat16).float().numpy()
+    y2 = F_.resize_bilinear_nhwc(F_.nchw_f32_to_nhwc_bf16(dev(x2)), 14, 22, align_corners=True)
+    assert np.abs(F_.nhwc_bf16_to_nchw_f32(y2, 32).cpu().numpy() - orc.resize_bilinear_align_corners(x2, 14, 22)).max() <= 2e-2

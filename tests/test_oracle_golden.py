@@ -177,3 +177,23 @@ def test_loss_mirror_golden(ss_golden):
                                    "sr_frames": torch.clip(torch.from_numpy(z["sr_frames"]), 0.0, 10.0)})
     assert abs(d["total"] - float(z["loss"])) <= 1e-6
     assert abs(d["l1"] - float(z["loss_l1"])) <= 1e-6 and abs(d["ssim"] - float(z["loss_ssim"])) <= 1e-6
+
+
+@pytest.fixture(scope="module")
+def temporal_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "temporal_ops.npz"))
+
+
+def test_temporal_ops_oracle_golden(temporal_golden):
+    """Operators of core/models/model_final.py: the oracle against outputs of the reference's own modules."""
+    z = temporal_golden
+    assert np.abs(orc.gradient_map(z["grad.x"]) - z["grad.y"]).max() <= 2e-6
+    for name in ("t64_64", "t192_192"):
+        y = orc.conv_transpose2x2s2(z[f"convT.{name}.x"], z[f"convT.{name}.w"], z[f"convT.{name}.b"], relu=True)
+        assert np.abs(y - z[f"convT.{name}.y"]).max() <= 2e-5, name
+    for key in [k[:-2] for k in z.files if k.startswith("tconv.") and k.endswith(".x")]:
+        k, st, pd = (int(v) for v in z[key + ".geom"])
+        y = orc.conv2d(z[key + ".x"], z[key + ".w"], z[key + ".b"], st, pd, act=1)
+        assert np.abs(y - z[key + ".y"]).max() <= 5e-5, key
+    assert np.abs(orc.resize_bilinear_align_corners(z["up2.x"], 10, 18) - z["up2.y"]).max() <= 2e-6
