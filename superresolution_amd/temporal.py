@@ -1,0 +1,345 @@
+"""Drop-in for the temporal variant ``core.models.model_final.SuperSampler``
+(core/models/model_final.py:430-519) on libsrhip.so: same constructor
+``SuperSampler(frame_ch, buffer_ch, sr_scale, n_history)``, same positional ``forward(lr_frame,
+hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer) -> (sr_frame, enhance_weight)``,
+the same module tree (hence identical ``state_dict`` keys/shapes and seed-for-seed initialisation:
+``xavier_normal_`` on every ``nn.Conv2d``, PyTorch defaults on the transposed convolutions).
+
+Execution (inference; raises under autograd): every convolution, transposed convolution, pixel
+(un)shuffle, warp, x2 up-sampling and the gradient map run on the HIP kernels, activations NHWC
+bf16.  3x3 / stride-1 layers with at most 64 input channels go to the MFMA kernel, the other
+shapes (1x1, stride 2, wider inputs; all at low resolution) to the direct kernel.  The disocclusion
+masks (model_final.py:53-139), the depth clamp (:40-46) and the attention mix (:422) are element-wise
+/ neighbourhood logic composed from torch tensor operations on the GPU, exactly as the reference
+writes them.  The warp is ``tools_math.backward_warping`` (the reference's own helper raises for every
+input; see that module).
+"""
+import math
+from typing import Tuple
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as TF
+
+from . import functional as F_
+from .tools_math import backward_warping_history
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's module tree
+# ------------------------------------------------------------------------------------------------
+class GradientMap(nn.Module):
+    def __init__(self, channels=None, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.eps = eps
+        kv = torch.tensor([[-1, -1, -1], [0, 0, 0], [1, 1, 1]], dtype=torch.float32).view(1, 1, 3, 3)
+        kh = torch.tensor([[-1, 0, 1], [-1, 0, 1], [-1, 0, 1]], dtype=torch.float32).view(1, 1, 3, 3)
+        if channels is not None:
+            kv, kh = kv.repeat(channels, 1, 1, 1), kh.repeat(channels, 1, 1, 1)
+        self.register_buffer("kernel_v", kv)
+        self.register_buffer("kernel_h", kh)
+
+
+class ConvActivation(nn.Sequential):
+    def __init__(self, cin: int, cout: int, kernel_size: int = 3, stride: int = 1, padding: int = 1) -> None:
+        super().__init__(nn.Conv2d(cin, cout, kernel_size, stride, padding), nn.ReLU(inplace=True))
+
+    def run(self, x: Tensor, res: Tensor = None) -> Tensor:
+        c = self[0]
+        return F_.conv2d_auto(x, c.weight.detach(), c.bias.detach(), stride=c.stride[0], padding=c.padding[0],
+                              act=F_.ACT_RELU, res=res)
+
+
+class TransConvActivation(nn.Sequential):
+    def __init__(self, cin: int, cout: int, kernel_size: int = 2, stride: int = 2, padding: int = 0) -> None:
+        super().__init__(nn.ConvTranspose2d(cin, cout, kernel_size, stride, padding), nn.ReLU(inplace=True))
+
+    def run(self, x: Tensor) -> Tensor:
+        c = self[0]
+        return F_.conv_transpose2x2s2(x, c.weight.detach(), c.bias.detach(), c.in_channels, act=F_.ACT_RELU)
+
+
+def _run_seq(seq: nn.Sequential, x: Tensor) -> Tensor:
+    for m in seq:
+        if isinstance(m, (ConvActivation, TransConvActivation)):
+            x = m.run(x)
+        elif isinstance(m, nn.Upsample):  # x2 bilinear, align_corners=True (model_final.py:281-289)
+            x = F_.resize_bilinear_nhwc(x, 2 * x.shape[1], 2 * x.shape[2], align_corners=True)
+        else:
+            raise TypeError(f"unexpected module {type(m).__name__}")
+    return x
+
+
+class FrameEncoder(nn.Module):
+    def __init__(self, cin: int, cout: int, inner: int = 24, return_head_feature: bool = False) -> None:
+        super().__init__()
+        self.conv_head = ConvActivation(cin, cout)
+        self.conv_main = nn.Sequential(ConvActivation(cout, cout), ConvActivation(cout, inner),
+                                       ConvActivation(inner, cout), ConvActivation(cout, cout))
+        self.return_head_feature = return_head_feature
+
+    def run(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        head = self.conv_head.run(x)
+        return _run_seq(self.conv_main, head), head
+
+
+class GBuffersEncoder(nn.Module):
+    def __init__(self, cin: int, cout: int, factor: int = 4) -> None:
+        super().__init__()
+        inner = cin * factor ** 2
+        self.factor = factor
+        self.fold = nn.PixelUnshuffle(factor)
+        self.conv_main = nn.Sequential(ConvActivation(inner, inner), ConvActivation(inner, inner, 1, padding=0),
+                                       ConvActivation(inner, inner, 1, padding=0), ConvActivation(inner, cout, 1, padding=0))
+        e = 7 * factor ** 2
+        self.conv_enhance = nn.Sequential(ConvActivation(e, e), ConvActivation(e, cout, 1, padding=0),
+                                          ConvActivation(cout, cout, 1, padding=0), ConvActivation(cout, cout, 1, padding=0))
+        self.enhance_param = nn.Parameter(torch.tensor(0.45), requires_grad=True)
+
+    def run(self, buffer: Tensor) -> Tensor:
+        """buffer (B,10,H,W) fp32 -> (B,h,w,cout) bf16 (model_final.py:250-258)."""
+        r2 = self.factor ** 2
+        folded = F_.pixel_unshuffle(buffer, self.factor)               # channel c*r2 + i*r + j
+        # normal (0:3), base colour (6:9) and depth (9:10) planes, folded
+        enh = torch.cat((folded[:, 0:3 * r2], folded[:, 6 * r2:9 * r2], folded[:, 9 * r2:10 * r2]), dim=1).contiguous()
+        fmap = _run_seq(self.conv_main, F_.nchw_f32_to_nhwc_bf16(folded))
+        e = F_.nchw_f32_to_nhwc_bf16(enh)
+        for m in list(self.conv_enhance)[:-1]:
+            e = m.run(e)
+        last = self.conv_enhance[-1][0]
+        # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
+        return F_.conv2d_direct(e, last.weight.detach(), last.bias.detach(), last.in_channels, act=F_.ACT_RELU,
+                                alpha=float(self.enhance_param), res=fmap)
+
+
+class HistoryRefiner(nn.Module):
+    def __init__(self, cin: int = 64, cout: int = 32, aux_channels: int = 16, down_chs=(32, 48, 64, 64),
+                 up_chs=(32, 32, 48, 64)) -> None:
+        super().__init__()
+        assert down_chs[0] == up_chs[0], "Output channels must be equal to the sum of the last two channels in the encoder."
+        self.refine_in = ConvActivation(cin, down_chs[0])
+        self.conv0 = ConvActivation(down_chs[0] + aux_channels, down_chs[0])
+        self.down0 = ConvActivation(down_chs[0], down_chs[1], 3, stride=2)
+        self.conv1 = ConvActivation(down_chs[1], down_chs[1])
+        self.down1 = ConvActivation(down_chs[1], down_chs[2], 3, stride=2)
+        self.conv2 = ConvActivation(down_chs[2], down_chs[2])
+        self.down2 = ConvActivation(down_chs[2], down_chs[3], 3, stride=2)
+        self.conv3 = ConvActivation(down_chs[3], down_chs[3])
+        up = lambda a, b: nn.Sequential(ConvActivation(a, b), nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True))
+        self.up3 = up(down_chs[3], up_chs[3])
+        self.up2 = up(up_chs[3], up_chs[2])
+        self.up1 = up(up_chs[2], up_chs[1])
+        self.up0 = ConvActivation(up_chs[1], up_chs[0])
+        self.refine_out = ConvActivation(up_chs[0], cout, 1, padding=0)
+
+    def run(self, x: Tensor, aux: Tensor, motion: Tensor) -> Tensor:
+        """x (N,h,w,64) bf16; aux (N,14,h,w), motion (N,2,h,w) fp32 (model_final.py:295-315)."""
+        x_in = self.refine_in.run(x)
+        extra = F_.nchw_f32_to_nhwc_bf16(torch.cat((aux, motion.abs()), dim=1).contiguous())   # 16 channels
+        x0 = self.conv0.run(F_.concat_nhwc(x_in, extra))
+        x1 = self.conv1.run(self.down0.run(x0))
+        x2 = self.conv2.run(self.down1.run(x1))
+        x3 = self.conv3.run(self.down2.run(x2))
+        u3 = _run_seq(self.up3, x3)
+        u2 = _run_seq(self.up2, F_.add_bf16(u3, x2))
+        u1 = _run_seq(self.up1, F_.add_bf16(u2, x1))
+        u0 = self.up0.run(F_.add_bf16(u1, x0))
+        return self.refine_out.run(F_.add_bf16(u0, x_in))
+
+
+class FusionNetwork(nn.Module):
+    def __init__(self, cin: int, first_channel=None, down_chs=(64, 128, 192, 256), up_chs=(64, 64, 128, 192)) -> None:
+        super().__init__()
+        first_channel = down_chs[0] if first_channel is None else first_channel
+        two = lambda a, b, c: nn.Sequential(ConvActivation(a, b), ConvActivation(b, c))
+        self.conv0 = two(cin, first_channel, down_chs[0])
+        self.down1 = ConvActivation(down_chs[0], down_chs[1], 3, stride=2)
+        self.conv1 = two(down_chs[1], down_chs[1], down_chs[1])
+        self.down2 = ConvActivation(down_chs[1], down_chs[2], 3, stride=2)
+        self.conv2 = two(down_chs[2], down_chs[2], down_chs[2])
+        self.down3 = ConvActivation(down_chs[2], down_chs[3], 3, stride=2)
+        self.conv3 = two(down_chs[3], down_chs[3], down_chs[3])
+        self.up3 = nn.Sequential(ConvActivation(down_chs[3], up_chs[3]), ConvActivation(up_chs[3], up_chs[3]),
+                                 TransConvActivation(up_chs[3], up_chs[3], 2, 2))
+        self.up2 = nn.Sequential(ConvActivation(up_chs[3] + down_chs[2], 2 * up_chs[2]), ConvActivation(2 * up_chs[2], up_chs[2]),
+                                 TransConvActivation(up_chs[2], up_chs[2], 2, 2))
+        self.up1 = nn.Sequential(ConvActivation(up_chs[2] + down_chs[1], 2 * up_chs[1]), ConvActivation(2 * up_chs[1], up_chs[1]),
+                                 TransConvActivation(up_chs[1], up_chs[1], 2, 2))
+        self.up0 = two(up_chs[1] + down_chs[0], up_chs[0], up_chs[0])
+
+    def run(self, x: Tensor) -> Tensor:
+        f0 = _run_seq(self.conv0, x)
+        f1 = _run_seq(self.conv1, self.down1.run(f0))
+        f2 = _run_seq(self.conv2, self.down2.run(f1))
+        f3 = _run_seq(self.conv3, self.down3.run(f2))
+        f3 = _run_seq(self.up3, f3)
+        f2 = _run_seq(self.up2, F_.concat_nhwc(f3, f2))
+        f1 = _run_seq(self.up1, F_.concat_nhwc(f2, f1))
+        return _run_seq(self.up0, F_.concat_nhwc(f1, f0))
+
+
+class Attention(nn.Module):
+    def __init__(self, cin: int, cout=None) -> None:
+        super().__init__()
+        cout = cin if cout is None else cout
+        self.conv = ConvActivation(cin, cout)
+        self.w_self = ConvActivation(cin, 1)
+        self.w_cross = ConvActivation(cin, 1)
+
+    def run(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        return self.conv.run(x), self.w_self.run(x)[..., 0:1], self.w_cross.run(x)[..., 0:1]
+
+
+class MainNetwork(nn.Module):
+    def __init__(self, basic_channels: int = 64, curr_channels: int = 64, hist_channels: int = 32,
+                 gbuffer_channels: int = 64, sr_scale: int = 4) -> None:
+        super().__init__()
+        assert curr_channels == hist_channels, "curr_channels and hist_channels must be the same"
+        self.sr_scale = sr_scale
+        self.grad_map = nn.Sequential(GradientMap(6), nn.PixelUnshuffle(sr_scale))
+        self.attn_grad = Attention(6 * sr_scale ** 2, basic_channels)
+        self.attn_fmap = Attention(basic_channels, basic_channels)
+        self.main_network = FusionNetwork(basic_channels + hist_channels + gbuffer_channels, basic_channels + gbuffer_channels)
+
+    def run(self, fmap_current: Tensor, fmap_history: Tensor, fmap_gbuffer: Tensor, hr_buffer: Tensor) -> Tensor:
+        grad_in = torch.cat((hr_buffer[:, 0:3], hr_buffer[:, 6:9]), dim=1).contiguous()
+        gmap = F_.pixel_unshuffle(F_.gradient_map(grad_in, self.grad_map[0].eps), self.sr_scale)
+        grad, g_self, g_cross = self.attn_grad.run(F_.nchw_f32_to_nhwc_bf16(gmap))
+        fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
+        # model_final.py:422 (element-wise, channel-broadcast gates)
+        cur = fmap_current.float() + torch.sigmoid(f_self.float() * g_cross.float()) * fmap.float() \
+            + torch.sigmoid(g_self.float() * f_cross.float()) * grad.float()
+        cur = cur.to(torch.bfloat16)
+        return self.main_network.run(F_.concat_nhwc(F_.concat_nhwc(cur, fmap_history), fmap_gbuffer))
+
+
+# ------------------------------------------------------------------------------------------------
+# disocclusion logic of the reference, composed from tensor operations (fp32 NCHW on the GPU)
+# ------------------------------------------------------------------------------------------------
+def clamp_depth(depth: Tensor, thres1: float = 3.0, thres2: float = 7.0) -> Tensor:
+    """model_final.py:40-46 without the host-side max() test (the formula is the identity below thres1)."""
+    return torch.where(depth >= thres2, thres1 + math.log2(thres2 - thres1) + torch.log10((depth - thres2) + 1),
+                       torch.where(depth >= thres1, thres1 + torch.log2((depth - thres1) + 1), depth))
+
+
+def _unfold_reflect(x: Tensor, ksize: int) -> Tensor:
+    pad = ksize // 2
+    xp = TF.pad(x, (pad, pad, pad, pad), mode="reflect")
+    return xp.unfold(2, ksize, 1).unfold(3, ksize, 1).reshape(*x.shape, ksize * ksize)
+
+
+def rgb_colour_distance(rgb1: Tensor, rgb2: Tensor) -> Tensor:
+    """core/tools/color.py:22-31 (including its channel naming: index 1 is called b, index 2 g)."""
+    r1, b1, g1 = rgb1[:, 0:1], rgb1[:, 1:2], rgb1[:, 2:3]
+    r2, b2, g2 = rgb2[:, 0:1], rgb2[:, 1:2], rgb2[:, 2:3]
+    r = (r1 + r2) / 2
+    dr, dg, db = r1 - r2, g1 - g2, b1 - b2
+    return torch.sqrt((2 + r) * dr ** 2 + 4 * dg ** 2 + (2 + (1 - r)) * db ** 2)
+
+
+def compute_mask_frame(current_frame: Tensor, history_frame: Tensor, ksize: int = 3) -> Tensor:
+    u = _unfold_reflect(current_frame, ksize)[:, None, ...]
+    mask = (history_frame < u.min(dim=-1)[0]) | (history_frame > u.max(dim=-1)[0])
+    return torch.all(mask, dim=2, keepdim=True)
+
+
+def compute_mask_basecolor(current_color: Tensor, history_color: Tensor, ksize: int = 3) -> Tensor:
+    b, f, c, h, w = history_color.shape
+    cur = _unfold_reflect(current_color.reshape(b * f, c, h, w), ksize)
+    hist = history_color.reshape(b * f, c, h, w)[..., None]
+    dist = rgb_colour_distance(cur, hist).view(b, f, 1, h, w, ksize * ksize)
+    return (dist > 0.5).float().mean(dim=-1) > 0.7
+
+
+def compute_mask_depth(current_depth: Tensor, history_depth: Tensor) -> Tensor:
+    return (current_depth - history_depth) > (0.1 * current_depth)
+
+
+def compute_mask_normal(current_normal: Tensor, history_normal: Tensor, thres: float = 0.707) -> Tensor:
+    dot = torch.sum(((current_normal - 0.5) * 2.0) * ((history_normal - 0.5) * 2.0), dim=2, keepdim=True)
+    return torch.logical_not(dot.abs() < 1e-3) & (dot < thres)
+
+
+def compute_mask_metallic(cur: Tensor, hist: Tensor, mark_max_value: float = 1000.0) -> Tensor:
+    return (cur > mark_max_value) | (torch.abs(cur - hist) > 0.25)
+
+
+def compute_mask_roughness(cur: Tensor, hist: Tensor, mark_min_value: float = -1000.0) -> Tensor:
+    return (cur < mark_min_value) | (torch.abs(cur - hist) > 0.25)
+
+
+# ------------------------------------------------------------------------------------------------
+class SuperSampler(nn.Module):
+    def __init__(self, frame_ch: int, buffer_ch: int, sr_scale: int, n_history: int) -> None:
+        super().__init__()
+        self.n_history = n_history
+        fr, bf = 64, 64
+        hs = fr // n_history
+        dw, up = [64, 128, 192, 256], [64, 64, 128, 192]
+        self.frame_encoder = FrameEncoder(frame_ch, fr, return_head_feature=True)
+        self.buffers_encoder = GBuffersEncoder(buffer_ch, bf, factor=sr_scale)
+        self.history_refiner = HistoryRefiner(fr, hs, aux_channels=(3 + 1 + 3) * 2 + 2)
+        self.main_network = MainNetwork(hist_channels=hs * n_history, sr_scale=sr_scale)
+        self.conv_out = nn.Sequential(nn.Conv2d(up[0] + dw[0], frame_ch * sr_scale ** 2, 3, 1, 1), nn.PixelShuffle(sr_scale),
+                                      nn.Conv2d(frame_ch, frame_ch, 3, 1, 1), nn.ReLU(inplace=True))
+        self.sr_scale, self.frame_ch = sr_scale, frame_ch
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        for m in self.modules():  # model_final.py:507-519 (transposed convolutions keep their default init)
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, lr_frame: Tensor, hr_buffer: Tensor, lr_buffer: Tensor, motion_vectors: Tensor,
+                history_frames: Tensor, history_buffer: Tensor) -> Tuple[Tensor, Tensor]:
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the temporal SuperSampler on libsrhip is inference-only: call it under torch.no_grad()")
+        return self.infer(lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer)
+
+    @torch.no_grad()
+    def infer(self, lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer):
+        # depth clamp, in place like the reference (model_final.py:462-463)
+        hr_buffer[:, -1] = clamp_depth(hr_buffer[:, -1])
+        lr_buffer[:, -1] = clamp_depth(lr_buffer[:, -1])
+        history_buffer[:, :, -1] = clamp_depth(history_buffer[:, :, -1])
+        assert hr_buffer.max() < 10, "Depth value is too large"
+
+        fmap_bf = self.buffers_encoder.run(hr_buffer.contiguous())
+        fmap_current, fmap_shadow = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(lr_frame.float().contiguous()))
+
+        b, f, _, h, w = history_frames.shape
+        warped_frames, warped_buffer, motion_vectors = backward_warping_history(motion_vectors, history_frames, history_buffer)
+
+        mask_frame = compute_mask_frame(lr_frame, warped_frames, ksize=5)
+        current_buffer = lr_buffer.view(b, 1, -1, h, w).expand_as(warped_buffer)
+        mask = mask_frame | compute_mask_basecolor(current_buffer[:, :, 6:9], warped_buffer[:, :, 6:9]) \
+            | compute_mask_depth(current_buffer[:, :, -1:], warped_buffer[:, :, -1:])
+        marked_frames = torch.where(mask, 0, warped_frames).view(b * f, -1, h, w)
+        marked_buffer = torch.where(mask, 0, warped_buffer)
+        aux_buffer = torch.cat((current_buffer[:, :, 0:3], current_buffer[:, :, 6:10], marked_buffer[:, :, 0:3],
+                                marked_buffer[:, :, 6:10]), dim=2).reshape(b * f, -1, h, w)
+        aux_motion = motion_vectors.reshape(b * f, -1, h, w)
+
+        fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames.float().contiguous()))[0]
+        fmap_history = self.history_refiner.run(fmap_history, aux_buffer, aux_motion)          # (b*f, h, w, hs)
+        if f > 1:  # (b, f*hs, h, w) in the reference: history index major, then channels
+            fmap_history = fmap_history.view(b, f, h, w, -1).permute(0, 2, 3, 1, 4).reshape(b, h, w, -1).contiguous()
+
+        fmap = self.main_network.run(fmap_current, fmap_history, fmap_bf, hr_buffer)
+        c0, c2 = self.conv_out[0], self.conv_out[2]
+        t = F_.conv2d_auto(F_.concat_nhwc(fmap, fmap_shadow), c0.weight.detach(), c0.bias.detach())
+        hr = F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale)
+        wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)
+        sr_frame = F_.conv3x3(F_.nchw_f32_to_nhwc_bf16(hr), wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)
+
+        mask_normal = compute_mask_normal(current_buffer[:, :, 0:3], warped_buffer[:, :, 0:3])
+        mask_rough = compute_mask_roughness(current_buffer[:, :, 5:6], warped_buffer[:, :, 5:6], mark_min_value=0.02)
+        mask_metal = compute_mask_metallic(current_buffer[:, :, 3:4], warped_buffer[:, :, 3:4], mark_max_value=0.95)
+        enhance_weight = torch.cat([mask_normal, mask_rough, mask_metal], dim=1).float().mean(dim=2, keepdim=True).mean(dim=1)
+        return sr_frame, enhance_weight

@@ -341,11 +341,72 @@ def gen_temporal_ops():
     print("temporal_ops.npz:", len(out), "arrays")
 
 
+def gen_temporal_model():
+    """Full forward of the temporal variant, core/models/model_final.py SuperSampler(3, 10, 4, 1), at LR 16x24.
+    The reference's backward_warping (core/tools/math.py:10-17) permutes an already (x, y)-last grid and
+    raises for every input; it is replaced here by the evidently intended form (same arithmetic, no permute)."""
+    torch.cuda.current_device = lambda: "cpu"
+    import core.tools.math as mutil
+    from torch.nn import functional as F
+
+    def warp_fixed(frame, motion, mode="nearest", align_corners=True):
+        h, w = frame.shape[-2:]
+        gx = torch.arange(w).view(1, w).expand(h, -1).float()
+        gy = torch.arange(h).view(h, 1).expand(-1, w).float()
+        gx = ((gx[None, ...] + motion[:, 0]) / (w - 1)) * 2.0 - 1.0
+        gy = ((gy[None, ...] + motion[:, 1]) / (h - 1)) * 2.0 - 1.0
+        return F.grid_sample(frame, torch.stack([gx, gy], dim=-1), mode, "zeros", align_corners)
+
+    mutil.backward_warping = warp_fixed
+    import core.models.model_final as mf
+    torch.manual_seed(42)
+    m = mf.SuperSampler(3, 10, 4, 1)
+    init = {name: np.concatenate([p.detach().reshape(-1)[:8].numpy(),
+                                  np.array([p.detach().double().sum().item()], np.float32)]).astype(np.float32)
+            for name, p in m.state_dict().items()}
+    g = torch.Generator().manual_seed(31)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(bf16_round(torch.randn(p.shape, generator=g) * 0.05))
+            elif p.dim() > 1:
+                p.copy_(bf16_round(p))
+    m.eval()
+    b, f, h, w, s = 1, 1, 16, 24, 4
+    lr_frame = rnd(g, b, 3, h, w, lo=0.0, hi=1.0)
+    hr_buffer = rnd(g, b, 10, h * s, w * s, lo=0.0, hi=1.0)
+    hr_buffer[:, 9] *= 5.0                       # depth beyond the first clamp threshold
+    lr_buffer = F.interpolate(hr_buffer, scale_factor=1.0 / s, mode="nearest")
+    motion = rnd(g, b, f, 2, h, w, lo=-2.0, hi=2.0)
+    hist_frames = (lr_frame[:, None] + 0.05 * rnd(g, b, f, 3, h, w)).clamp(0, 1)
+    hist_buffer = (lr_buffer[:, None] + 0.02 * rnd(g, b, f, 10, h, w)).clamp(0, 6)
+    out = {"lr_frame": lr_frame.numpy(), "hr_buffer": hr_buffer.numpy(), "lr_buffer": lr_buffer.numpy(),
+           "motion": motion.numpy(), "hist_frames": hist_frames.numpy(), "hist_buffer": hist_buffer.numpy()}
+    with torch.no_grad():
+        sr, ew = m(lr_frame.clone(), hr_buffer.clone(), lr_buffer.clone(), motion.clone(), hist_frames.clone(), hist_buffer.clone())
+    out["sr"] = sr.numpy(); out["enhance_weight"] = ew.numpy()
+    out["keys"] = np.array(list(m.state_dict().keys()))
+    # 6.8 M weights are not stored: they are bf16_round(seed-42 initialisation), which the mirror reproduces
+    # seed for seed (checked through the digests below); biases and the scalar parameter are stored.
+    for k, v in m.state_dict().items():
+        out["init." + k] = init[k]
+        if v.dim() <= 1:
+            out["small." + k] = v.detach().numpy()
+        else:
+            out["digest." + k] = np.array([v.detach().double().sum().item(), v.detach().double().abs().sum().item()])
+    np.savez_compressed(os.path.join(OUT, "temporal_model.npz"), **out)
+    print("temporal_model.npz: sr", tuple(sr.shape), "mean", sr.abs().mean().item(), "enhance_weight", tuple(ew.shape),
+          "params", sum(p.numel() for p in m.parameters()))
+
+
 if __name__ == "__main__":
     _stub_modules()
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "reprfn_init":
         gen_reprfn_init()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "temporal_model":
+        gen_temporal_model()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_ops":
         gen_temporal_ops()
@@ -355,3 +416,4 @@ if __name__ == "__main__":
     gen_reprfn()
     gen_reprfn_init()
     gen_temporal_ops()
+    gen_temporal_model()
