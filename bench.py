@@ -221,6 +221,8 @@ def run_train(args, world, rank, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(loss))
+    # every rank runs the instrumented extra steps: they contain the gradient all-reduce
+    k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, S, 2)
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3
@@ -229,7 +231,6 @@ def run_train(args, world, rank, dev, dist):
     # backward = dgrad + wgrad of every layer except the data gradient of the two input layers
     no_dgrad = 2 * 9 * (10 * 64 * p_hr + 3 * 32 * p_lr)
     flop_step = 3 * fwd - no_dgrad
-    k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, S, 2)
     k_flop = 2.0 * B * S * S * 64 * 64 * 9
     res = {
         "metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs",
@@ -256,12 +257,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") with one GPU per rank; SRHIP_DIST_BACKEND=gloo rehearses the multi-rank path on a
+        # box with fewer GPUs than ranks (ranks then share a device)
+        backend = os.environ.get("SRHIP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload == "train":
         run_train(args, world, rank, dev, dist)
