@@ -537,7 +537,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                     if constexpr (C::SPREAD) {
                         // gap 0: staging read-back of the store group the next two taps finish;
                         // gaps 1..KC: pixel fragments of the next tap
-                        if constexpr (ml == 0 && !C::OUT_F32 && (t % 2 == 0) && (t / 2 < C::NST)) epi_read(IntC<t / 2>{});
+                        if constexpr (ml == 0 && !C::OUT_F32 && (t % 2 == 0) && (t / 2 < C::NST)) epi_read(IntC<t / 2 + 0 * ml>{});  // + 0 * ml: dependent, so the dead branch is not instantiated
                         if constexpr (ml >= 1 && ml <= C::KC) {
                             constexpr int kr = ml - 1;
                             if (t < 8 || i + 1 < nout)
@@ -550,18 +550,21 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                         constexpr int S = decltype(s_c)::value;
                         constexpr int E = C::epi_steps(t);
                         if constexpr (S < E) {
+                            constexpr int KD = KG + 0 * S;  // dependent on S: dead branches are not instantiated
                             if constexpr (t & 1) {
-                                constexpr int W0 = (KG == 0 && C::HAS_RES) ? 1 : 0;
+                                constexpr int W0 = (KD == 0 && C::HAS_RES) ? 1 : 0;
                                 if constexpr (S < W0) epi_res_wait(IntC<PAR ^ 1>{}, IntC<0>{});
-                                else epi_elem(IntC<KG>{}, IntC<S - W0>{}, IntC<PAR ^ 1>{});
+                                else epi_elem(IntC<KD>{}, IntC<S - W0>{}, IntC<PAR ^ 1>{});
                             } else {
-                                if constexpr (S < 4) epi_elem(IntC<KG>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
-                                else epi_store(IntC<KG>{}, st_soff);
+                                if constexpr (S < 4) epi_elem(IntC<KD>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
+                                else epi_store(IntC<KD>{}, st_soff);
                             }
                         } else if constexpr (S < E + C::dma_in_tap(t)) {
-                            issue_piece(IntC<t>{}, dma_s0, dma_s1, dma_slot);
+                            constexpr int TD = t + 0 * S;  // dependent on S: the dead branch is not instantiated
+                            issue_piece(IntC<TD>{}, dma_s0, dma_s1, dma_slot);
                         } else {
-                            resv[PAR][t] = buffer_load_b128_async(res_srd, vox[t], res_soff);
+                            constexpr int TR = t + 0 * S;
+                            resv[PAR][TR] = buffer_load_b128_async(res_srd, vox[TR], res_soff);
                         }
                     });
                     if constexpr (NS > 0) __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written

@@ -22,7 +22,7 @@ ONLY_64 = [("    SRHIP_CONV_CASE(1, 1, 1)\n    SRHIP_CONV_CASE(2, 1, 1)\n    SRH
 
 NO_BARRIER = [("            __builtin_amdgcn_s_barrier();\n\n            const int y = y0 + i;", "            const int y = y0 + i;")]
 NO_EPI2 = [("constexpr bool EPI = !C::OUT_F32 && t >= 1 && KG < C::NST;", "constexpr bool EPI = false && KG < C::NST;")]
-NO_DMA = [("                            issue_piece(IntC<t>{}, dma_s0, dma_s1, dma_slot);", "                            (void)dma_s0; (void)dma_s1; (void)dma_slot;"),
+NO_DMA = [("                            issue_piece(IntC<TD>{}, dma_s0, dma_s1, dma_slot);", "                            (void)dma_s0; (void)dma_s1; (void)dma_slot;"),
           ("            if (i == 0) {\n                vm_wait<0>();\n            } else if (i < C::LA - 2) {", "            if (true) {\n            } else if (i < C::LA - 2) {")]
 DMA_CACHED = [("            soff0 = yin ? pix * (unsigned)(csrc0 * 2) : kOobOffset;", "            soff0 = yin ? (pix & 0xfffu) * (unsigned)(csrc0 * 2) : kOobOffset;")]
 NO_STORE = [("            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);", "            if (store_soff == 12345u) __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);")]
