@@ -56,12 +56,15 @@ struct WCfg {
     static constexpr int XA = 4, ZA = 2;          // rows issued ahead
     static constexpr int XRING = XA + 1, ZRING = ZA + 1;
     static constexpr int Z_BASE = XRING * X_SLOT;
-    static constexpr int LDS_BYTES = Z_BASE + ZRING * Z_SLOT;
+    static constexpr int SINK_OFF = Z_BASE + ZRING * Z_SLOT;     // 1 KiB sink of the DMA pieces a wave does not own
+    static constexpr int LDS_BYTES = SINK_OFF + 1024;
     static constexpr int MAXPX = (XNP + NWAVES - 1) / NWAVES, MINPX = XNP / NWAVES;
     static constexpr int MAXPZ = (ZNP + NWAVES - 1) / NWAVES, MINPZ = ZNP / NWAVES;
-    // Top of iteration i needs x row i+2 and dz row i, both issued in iteration i-2; the younger
-    // operations of this wave are at least one whole iteration.
-    static constexpr int TOP_WAIT = MINPX + MINPZ;
+    // Every wave issues exactly MAXPX + MAXPZ pieces per iteration (a piece it does not own goes,
+    // all-out-of-range, to the sink), one per tap, x pieces first.  Top of iteration i needs x row i+2
+    // and dz row i, both issued in iteration i-2: younger is exactly one whole iteration.
+    static constexpr int TOP_WAIT = MAXPX + MAXPZ;
+    static_assert(MAXPX + MAXPZ <= 9, "one LDS-DMA piece per tap");
     static_assert(XA >= 4 && ZA >= 2, "wait counts assume rows are issued two iterations ahead");
 };
 
@@ -88,6 +91,16 @@ __device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr)
     bf16x4 r;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
     return r;
+}
+template <int V>
+struct WIntC { static constexpr int value = V; };
+template <int B, int E, class F>
+__device__ __forceinline__ void wg_static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(WIntC<B>{});
+        wg_static_for<B + 1, E>(f);
+    }
 }
 __device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi)
 {
@@ -180,73 +193,93 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
             const int col = x0 + px;
             zoff[m] = col < W ? (unsigned)(col * C::ZPB + c * 16) : kOob;
         }
-        // x row r <-> image row y0 - 1 + r (r = 0 .. nout+1); dz row r <-> image row y0 + r
-        auto issue_x = [&](const int r) {
+        // x row r <-> image row y0 - 1 + r (r = 0 .. nout+1); dz row r <-> image row y0 + r.
+        // Piece m (0 .. MAXPX+MAXPZ-1) of a row pair: x pieces first, then dz pieces; branch-free.
+        auto x_soff = [&](const int r) {
             const int y = y0 - 1 + r;
-            const unsigned soff = (y >= 0 && y < H && r < nout + 2) ? (unsigned)(y * W) * (unsigned)C::XPB : kOob;
-            char* slot = smem + (r % C::XRING) * C::X_SLOT;
-#pragma unroll
-            for (int m = 0; m < C::MAXPX; ++m) {
-                const int qq = wave + m * C::NWAVES;
-                if (qq < C::XNP)
-                    wg_lds_dma(rsrc_x, (__attribute__((address_space(3))) void*)(slot + qq * 1024), xoff[m], soff);
-            }
+            const bool in = (y >= 0) & (y < H) & (r < nout + 2);
+            return in ? (unsigned)(y * W) * (unsigned)C::XPB : kOob;
         };
-        auto issue_z = [&](const int r) {
-            const unsigned soff = (r < nout) ? (unsigned)((y0 + r) * W) * (unsigned)C::ZPB : kOob;
-            char* slot = smem + C::Z_BASE + (r % C::ZRING) * C::Z_SLOT;
-#pragma unroll
-            for (int m = 0; m < C::MAXPZ; ++m) {
+        auto z_soff = [&](const int r) { return (r < nout) ? (unsigned)((y0 + r) * W) * (unsigned)C::ZPB : kOob; };
+        auto issue_piece = [&](auto m_c, const unsigned xsoff, const unsigned xslot, const unsigned zsoff, const unsigned zslot) {
+            constexpr int m = decltype(m_c)::value;
+            if constexpr (m < C::MAXPX) {
                 const int qq = wave + m * C::NWAVES;
-                if (qq < C::ZNP)
-                    wg_lds_dma(rsrc_z, (__attribute__((address_space(3))) void*)(slot + qq * 1024), zoff[m], soff);
+                const unsigned off = (qq < C::XNP) ? xslot + (unsigned)qq * 1024u : (unsigned)C::SINK_OFF;
+                wg_lds_dma(rsrc_x, (__attribute__((address_space(3))) void*)(smem + off), (qq < C::XNP) ? xoff[m] : kOob, xsoff);
+            } else {
+                constexpr int mz = m - C::MAXPX;
+                const int qq = wave + mz * C::NWAVES;
+                const unsigned off = (qq < C::ZNP) ? zslot + (unsigned)qq * 1024u : (unsigned)C::SINK_OFF;
+                wg_lds_dma(rsrc_z, (__attribute__((address_space(3))) void*)(smem + off), (qq < C::ZNP) ? zoff[mz] : kOob, zsoff);
             }
         };
 
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous item's rows
 #pragma unroll 1
-        for (int r = 0; r < C::XA; ++r) issue_x(r);
+        for (int r = 0; r < C::XA; ++r) {
+            const unsigned so = x_soff(r);
+            wg_static_for<0, C::MAXPX>([&](auto m_c) { issue_piece(m_c, so, (unsigned)(r * C::X_SLOT), 0u, 0u); });
+        }
 #pragma unroll 1
-        for (int r = 0; r < C::ZA; ++r) issue_z(r);
+        for (int r = 0; r < C::ZA; ++r) {
+            const unsigned so = z_soff(r);
+            wg_static_for<C::MAXPX, C::MAXPX + C::MAXPZ>([&](auto m_c) { issue_piece(m_c, 0u, 0u, so, (unsigned)(C::Z_BASE + r * C::Z_SLOT)); });
+        }
+        int xpos = 0, zpos = 0;  // ring slots of x row i and dz row i
 
 #pragma unroll 1
         for (int i = 0; i < nout; ++i) {
             if (i < 2) wg_vm_wait<0>();
             else wg_vm_wait<C::TOP_WAIT>();
             __builtin_amdgcn_s_barrier();
-            issue_x(i + C::XA);
-            issue_z(i + C::ZA);
+            // rows fetched during this iteration go to the slots that row i-1 just left
+            const unsigned dxs = x_soff(i + C::XA), dzs = z_soff(i + C::ZA);
+            const unsigned dxslot = (unsigned)((xpos == 0 ? C::XRING - 1 : xpos - 1) * C::X_SLOT);
+            const unsigned dzslot = (unsigned)(C::Z_BASE + (zpos == 0 ? C::ZRING - 1 : zpos - 1) * C::Z_SLOT);
 
-            const unsigned zs = (unsigned)((i % C::ZRING) * C::Z_SLOT);
-            unsigned xs[3];
+            // per-row read bases: everything else is an immediate offset of the LDS instruction
+            unsigned xb[3][3][2], zb[2];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) xs[ky] = (unsigned)(((i + ky) % C::XRING) * C::X_SLOT);
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sl = xpos + ky;
+                const unsigned rowoff = (unsigned)((sl >= C::XRING ? sl - C::XRING : sl) * C::X_SLOT);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    xb[ky][kx][0] = xaddr[kx][0] + rowoff;
+                    xb[ky][kx][1] = xaddr[kx][1] + rowoff;
+                }
+            }
+            zb[0] = zaddr[0] + (unsigned)(zpos * C::Z_SLOT);
+            zb[1] = zaddr[1] + (unsigned)(zpos * C::Z_SLOT);
+            xpos = (xpos + 1 == C::XRING) ? 0 : xpos + 1;
+            zpos = (zpos + 1 == C::ZRING) ? 0 : zpos + 1;
 
             // dz fragments of this row (reused by all 9 taps)
             bf16x4 alo[C::NKS], ahi[C::NKS];
-#pragma unroll
-            for (int s = 0; s < C::NKS; ++s) {
-                alo[s] = lds_read_tr<0>(zaddr[0] + zs + s * 16 * C::ZPB);
-                ahi[s] = lds_read_tr<0>(zaddr[1] + zs + s * 16 * C::ZPB);
-            }
+            wg_static_for<0, C::NKS>([&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                alo[s] = lds_read_tr<s * 16 * C::ZPB>(zb[0]);
+                ahi[s] = lds_read_tr<s * 16 * C::ZPB>(zb[1]);
+            });
             // x fragments run one step ahead of the MFMAs
             constexpr int NSTEP = 9 * C::NKS;
             bf16x4 blo[2], bhi[2];
-            blo[0] = lds_read_tr<0>(xaddr[0][0] + xs[0]);
-            bhi[0] = lds_read_tr<0>(xaddr[0][1] + xs[0]);
-#pragma unroll
-            for (int st = 0; st < NSTEP; ++st) {
-                const int t = st / C::NKS, s = st % C::NKS;
-                const int cur = st & 1, nxt = cur ^ 1;
-                if (st + 1 < NSTEP) {
-                    const int tn = (st + 1) / C::NKS, sn = (st + 1) % C::NKS;
-                    blo[nxt] = lds_read_tr<0>(xaddr[tn % 3][0] + xs[tn / 3] + sn * 16 * C::XPB);
-                    bhi[nxt] = lds_read_tr<0>(xaddr[tn % 3][1] + xs[tn / 3] + sn * 16 * C::XPB);
+            blo[0] = lds_read_tr<0>(xb[0][0][0]);
+            bhi[0] = lds_read_tr<0>(xb[0][0][1]);
+            wg_static_for<0, NSTEP>([&](auto st_c) {
+                constexpr int st = decltype(st_c)::value;
+                constexpr int t = st / C::NKS, s = st % C::NKS;
+                constexpr int cur = st & 1, nxt = cur ^ 1;
+                if constexpr (st + 1 < NSTEP) {
+                    constexpr int tn = (st + 1) / C::NKS, sn = (st + 1) % C::NKS;
+                    blo[nxt] = lds_read_tr<sn * 16 * C::XPB>(xb[tn / 3][tn % 3][0]);
+                    bhi[nxt] = lds_read_tr<sn * 16 * C::XPB>(xb[tn / 3][tn % 3][1]);
                     wg_lds_wait<2>();
                 } else {
                     wg_lds_wait<0>();
                 }
-                if (st == 0) {
+                if constexpr (st == 0) {
 #pragma unroll
                     for (int k = 0; k < C::NKS; ++k) asm volatile("" : "+v"(alo[k]), "+v"(ahi[k]));
                 }
@@ -254,8 +287,12 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                 const bf16x8 a = join(alo[s], ahi[s]);
                 const bf16x8 b = join(blo[cur], bhi[cur]);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-                if (t == 4 && cit == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);
-            }
+                if constexpr (t == 4) {
+                    if (cit == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);
+                }
+                // one LDS-DMA piece per tap, after the tap's first MFMA
+                if constexpr (s == 0 && t < C::MAXPX + C::MAXPZ) issue_piece(WIntC<t + 0 * st>{}, dxs, dxslot, dzs, dzslot);
+            });
         }
         wg_vm_wait<0>();  // look-ahead rows past the item's end were issued as all-zero rows
     }
