@@ -102,6 +102,20 @@ __device__ __forceinline__ void wg_static_for(F&& f)
         wg_static_for<B + 1, E>(f);
     }
 }
+// MFMA as asm with the accumulator of tile T pinned to the fixed registers a[16T : 16T+15]: accumulators
+// never move between register files (a copy right before an asm MFMA would be a hazard the compiler cannot
+// see), and no hazard padding is added between the empty asm that ties the fragment registers to the
+// counted LDS wait and the instruction that consumes them.  The leading s_nop covers a register copy the
+// compiler may still place right in front of the operands.
+template <int T>
+__device__ __forceinline__ void wg_mfma(f32x16& acc, const bf16x8& a, const bf16x8& b)
+{
+#define WG_ACC_CASE(TI, RANGE) \
+    if constexpr (T == TI) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+{a[" RANGE "]}"(acc) : "v"(a), "v"(b));
+    WG_ACC_CASE(0, "0:15") WG_ACC_CASE(1, "16:31") WG_ACC_CASE(2, "32:47") WG_ACC_CASE(3, "48:63") WG_ACC_CASE(4, "64:79")
+    WG_ACC_CASE(5, "80:95") WG_ACC_CASE(6, "96:111") WG_ACC_CASE(7, "112:127") WG_ACC_CASE(8, "128:143") WG_ACC_CASE(9, "144:159")
+#undef WG_ACC_CASE
+}
 __device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi)
 {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -154,6 +168,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (short)0x3f80;
+    asm volatile("" : "+v"(ones));  // opaque: stays in four registers instead of being rebuilt next to its (asm) consumer
 
     for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
         const int strip = item % p.nstrips;
@@ -286,9 +301,9 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                 asm volatile("" : "+v"(blo[cur]), "+v"(bhi[cur]));  // consumers stay behind the wait
                 const bf16x8 a = join(alo[s], ahi[s]);
                 const bf16x8 b = join(blo[cur], bhi[cur]);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                wg_mfma<t>(acc[t], a, b);
                 if constexpr (t == 4) {
-                    if (cit == 0) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, accb, 0, 0, 0);
+                    if (cit == 0) wg_mfma<9>(accb, a, ones);
                 }
                 // one LDS-DMA piece per tap, after the tap's first MFMA
                 if constexpr (s == 0 && t < C::MAXPX + C::MAXPZ) issue_piece(WIntC<t + 0 * st>{}, dxs, dxslot, dzs, dzslot);
@@ -297,6 +312,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
         wg_vm_wait<0>();  // look-ahead rows past the item's end were issued as all-zero rows
     }
 
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // last MFMA results -> the reads below (hazard invisible inside asm)
     // ---- partial tiles -> workspace [workgroup][wave][10][16 registers][64 lanes]
     float* out = p.partial + ((size_t)(blockIdx.x * C::NWAVES + wave) * 10) * 1024 + lane;
 #pragma unroll
