@@ -4,7 +4,8 @@
 
 Default workload (BASELINE.json configs[1]): 4x SR inference 540p -> 2160p (4K), batch 1, bf16
 compute, default network (core/models/model.py SuperSampler), synthetic frames, seed-42 weights.
-A step = one forward pass over one frame whose inputs are already resident in HBM.  With N > 1
+A step = one forward pass over one frame whose inputs are already resident in HBM.  The same run then
+times the training step (the second half of the metric) and reports it in a `train` block of the line.  With N > 1
 ranks (one process per GPU, launched by torch.distributed.run) frames are sharded across ranks
 with no data-path collective (weak scaling); the value is whole-job frames/s.
 
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training leg of the default workload")
+    ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training leg of the default workload")
     ap.add_argument("--train-batch", type=int, default=16, help="crops per GPU per step (train workload)")
     ap.add_argument("--train-crop", type=int, default=1024, help="HR crop size (train workload)")
     ap.add_argument("--cpu-train-crop", type=int, default=512, help="HR crop size of the CPU-oracle training sample")
@@ -173,7 +176,10 @@ def cpu_baseline_train(crop):
                       f"scaled by pixel count to 1024x1024 crops"}
 
 
-def run_train(args, world, rank, dev, dist):
+def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=True):
+    """Times the training step on every rank; returns the result line (rank 0) or None."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     from superresolution_amd import functional as F_
     from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters
     from superresolution_amd.loss import FusedLossGroup
@@ -202,14 +208,14 @@ def run_train(args, world, rank, dev, dist):
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -224,8 +230,8 @@ def run_train(args, world, rank, dev, dist):
     # every rank runs the instrumented extra steps: they contain the gradient all-reduce
     k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, S, 2)
     if rank != 0:
-        return
-    ms_per_step = dt / args.steps * 1e3
+        return None
+    ms_per_step = dt / steps * 1e3
     p_hr, p_lr = B * S * S, B * (S // SCALE) ** 2
     fwd = FLOP_PER_HR_PX * p_hr + FLOP_PER_LR_PX * p_lr
     # backward = dgrad + wgrad of every layer except the data gradient of the two input layers
@@ -234,8 +240,8 @@ def run_train(args, world, rank, dev, dist):
     k_flop = 2.0 * B * S * S * 64 * 64 * 9
     res = {
         "metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs",
-        "value": world * B * args.steps / dt, "unit": "crops/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "value": world * B * steps / dt, "unit": "crops/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"training step on {B} HR crops of {S}x{S} per GPU (LR {S // SCALE}x{S // SCALE}, scale 4): "
                                "nearest down-sampling + forward + clip + L1 + 0.5*SSIM + backward + gradient all-reduce + AdamW, "
@@ -247,9 +253,9 @@ def run_train(args, world, rank, dev, dist):
                                    "runs every data gradient)", k_flop, 2.0 * B * S * S * 64 * 2, k_avg_ms, k_med_ms,
                                    k_launches, None),
     }
-    if not args.no_cpu_baseline:
+    if with_cpu and not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_train(args.cpu_train_crop)
-    print(json.dumps(res), flush=True)
+    return res
 
 
 def main():
@@ -271,7 +277,9 @@ def main():
             dist.init_process_group(backend)
 
     if args.workload == "train":
-        run_train(args, world, rank, dev, dist)
+        res = run_train(args, world, rank, dev, dist)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -302,11 +310,24 @@ def main():
         dt = float(t.item())
     assert out.shape == (1, 3, HR_H, HR_W) and bool(torch.isfinite(out).all())
 
+    # every rank takes part in the instrumented passes and in the training leg (gradient all-reduce)
+    k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, HR_H, 5)
+    train = None
+    if not args.no_train:
+        del out
+        torch.cuda.empty_cache()
+        try:
+            train = run_train(args, world, rank, dev, dist, steps=args.train_steps, warmup=2, with_cpu=False)
+            if train is not None:
+                train = {k: train[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "roofline")}
+        except Exception as e:  # the headline line must still be printed
+            if world > 1:
+                raise       # a rank that dropped out of a collective cannot be papered over
+            train = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         fps = world * args.steps / dt
         flop_frame = FLOP_PER_HR_PX * HR_H * HR_W + FLOP_PER_LR_PX * LR_H * LR_W
-        k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, HR_H, 5)
         k_flop = 2.0 * HR_H * HR_W * 64 * 64 * 9
         res = {
             "metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs",
@@ -322,7 +343,9 @@ def main():
                                        "12 of the 25 HR launches per frame)", k_flop, 2.0 * HR_H * HR_W * 64 * 2,
                                        k_avg_ms, k_med_ms, k_launches, measured_traffic_bytes()),
         }
-        if not args.no_cpu_baseline:
+        if train is not None:
+            res["train"] = train   # second half of the metric: train crops/s at this GPU count (weak scaling)
+        if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_crop)
         print(json.dumps(res), flush=True)
     if dist is not None:
