@@ -35,8 +35,9 @@ __device__ __forceinline__ float coord_val(CoordAxis a, int j) {
 }
 // ATen grid_sampler unnormalize
 __device__ __forceinline__ float unnorm(float c, int size, bool align) {
-    return align ? __fmul_rn(__fdiv_rn(__fadd_rn(c, 1.0f), 2.0f), (float)(size - 1))
-                 : __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(c, 1.0f), (float)size), 1.0f), 2.0f);
+    // division by 2 is exact in binary floating point, so * 0.5f is the same rounding as ATen's / 2
+    return align ? __fmul_rn(__fmul_rn(__fadd_rn(c, 1.0f), 0.5f), (float)(size - 1))
+                 : __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(c, 1.0f), (float)size), 1.0f), 0.5f);
 }
 
 struct Taps {  // bilinear footprint with zero padding
@@ -138,22 +139,18 @@ __device__ __forceinline__ void blend8(const unsigned short* __restrict__ src, l
 }
 
 __global__ void upsample_nhwc_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
-                                     int n, int c, int sh, int sw, int th, int tw, CoordAxis ax, CoordAxis ay)
+                                     int c, int sh, int sw, int th, int tw, CoordAxis ax, CoordAxis ay)
 {
-    const int cg = c / 8;
-    const long long total = (long long)n * th * tw * cg;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        long long p = i / cg;
-        const int x = (int)(p % tw); p /= tw;
-        const int y = (int)(p % th);
-        const int img = (int)(p / th);
-        const float ix = unnorm(coord_val(ax, x), sw, false);
-        const float iy = unnorm(coord_val(ay, y), sh, false);
-        const Taps t = make_taps(ix, iy, sw, sh);
-        blend8(src, (long long)img * sh * sw, sw, c, g * 8, t, dst + (((long long)img * th + y) * tw + x) * c + g * 8);
-    }
+    // grid: (chunks of a target row, target row, image): no 64-bit index arithmetic per thread
+    const unsigned cg = (unsigned)c / 8u;
+    const unsigned xi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xi >= (unsigned)tw * cg) return;
+    const int x = (int)(xi / cg), g = (int)(xi - (unsigned)x * cg);
+    const int y = blockIdx.y, img = blockIdx.z;
+    const float ix = unnorm(coord_val(ax, x), sw, false);
+    const float iy = unnorm(coord_val(ay, y), sh, false);
+    const Taps t = make_taps(ix, iy, sw, sh);
+    blend8(src, (long long)img * sh * sw, sw, c, g * 8, t, dst + (((long long)img * th + y) * tw + x) * c + g * 8);
 }
 
 // Backward of upsample_nhwc_kernel as a gather: one thread = one SOURCE pixel x 8 channels.  Every
@@ -364,34 +361,29 @@ __global__ void gradient_map_kernel(const float* __restrict__ src, float* __rest
 }
 
 __global__ void warp_nhwc_kernel(const unsigned short* __restrict__ frame, const float* __restrict__ motion,
-                                 unsigned short* __restrict__ dst, int n, int c, int h, int w, int mode, int align)
+                                 unsigned short* __restrict__ dst, int c, int h, int w, int mode, int align)
 {
-    const int cg = c / 8;
+    const unsigned cg = (unsigned)c / 8u;
+    const unsigned xi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xi >= (unsigned)w * cg) return;
+    const int x = (int)(xi / cg), g = (int)(xi - (unsigned)x * cg);
+    const int y = blockIdx.y, img = blockIdx.z;
     const long long hw = (long long)h * w;
-    const long long total = (long long)n * hw * cg;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        long long p = i / cg;
-        const int x = (int)(p % w); p /= w;
-        const int y = (int)(p % h);
-        const int img = (int)(p / h);
-        const float mx = motion[((long long)img * 2 + 0) * hw + (long long)y * w + x];
-        const float my = motion[((long long)img * 2 + 1) * hw + (long long)y * w + x];
-        const float gx = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)x, mx), (float)(w - 1)), 2.0f), 1.0f);
-        const float gy = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)y, my), (float)(h - 1)), 2.0f), 1.0f);
-        const float ix = unnorm(gx, w, align), iy = unnorm(gy, h, align);
-        unsigned short* o = dst + (((long long)img * h + y) * w + x) * c + g * 8;
-        if (mode == SRHIP_BILINEAR) {
-            const Taps t = make_taps(ix, iy, w, h);
-            blend8(frame, (long long)img * hw, w, c, g * 8, t, o);
-        } else {
-            const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (xn >= 0 && xn < w && yn >= 0 && yn < h)
-                v = *(const uint4*)(frame + ((long long)img * hw + (long long)yn * w + xn) * c + g * 8);
-            *(uint4*)o = v;
-        }
+    const float mx = motion[((long long)img * 2 + 0) * hw + (long long)y * w + x];
+    const float my = motion[((long long)img * 2 + 1) * hw + (long long)y * w + x];
+    const float gx = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)x, mx), (float)(w - 1)), 2.0f), 1.0f);
+    const float gy = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)y, my), (float)(h - 1)), 2.0f), 1.0f);
+    const float ix = unnorm(gx, w, align), iy = unnorm(gy, h, align);
+    unsigned short* o = dst + (((long long)img * h + y) * w + x) * c + g * 8;
+    if (mode == SRHIP_BILINEAR) {
+        const Taps t = make_taps(ix, iy, w, h);
+        blend8(frame, (long long)img * hw, w, c, g * 8, t, o);
+    } else {
+        const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (xn >= 0 && xn < w && yn >= 0 && yn < h)
+            v = *(const uint4*)(frame + ((long long)img * hw + (long long)yn * w + xn) * c + g * 8);
+        *(uint4*)o = v;
     }
 }
 
@@ -402,13 +394,14 @@ __global__ void sample_f32_kernel(const float* __restrict__ src, const float* __
                                   float* __restrict__ dst, int n, int c, int sh, int sw, int th, int tw, int mode,
                                   int align, CoordAxis ax, CoordAxis ay)
 {
+    // grid: (chunks of a target row, target row, image)
     const long long thw = (long long)th * tw, shw = (long long)sh * sw;
-    const long long total = (long long)n * thw;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int img = (int)(i / thw);
-        const long long pix = i - (long long)img * thw;
-        const int y = (int)(pix / tw), x = (int)(pix - (long long)y * tw);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= tw) return;
+    const int y = blockIdx.y, img = blockIdx.z;
+    (void)n;
+    {
+        const long long pix = (long long)y * tw + x;
         float gx, gy;
         if (GRID_FROM == 0) {
             gx = coord_val(ax, x); gy = coord_val(ay, y);
@@ -494,57 +487,66 @@ __global__ void sample_bwd_f32_kernel(const float* __restrict__ src, const float
 // pixel shuffle / unshuffle (pure permutations), nearest down-sampling
 // ------------------------------------------------------------------------------------------
 template <typename T, bool UNSHUFFLE>
-__global__ void pixel_shuffle_kernel(const T* __restrict__ src, T* __restrict__ dst, int n, int c, int h, int w, int r)
+__global__ void pixel_shuffle_kernel(const T* __restrict__ src, T* __restrict__ dst, int c, int h, int w, int r, int vec)
 {
-    // "big" tensor (N,C,H*r,W*r), "deep" tensor (N,C*r*r,H,W); thread index runs over the big one.
-    const long long total = (long long)n * c * h * r * w * r;
-    const int wr = w * r, hr = h * r;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int X = (int)(i % wr);
-        long long t = i / wr;
-        const int Y = (int)(t % hr); t /= hr;
-        const int ch = (int)(t % c);
-        const int img = (int)(t / c);
-        const int yy = Y / r, ii = Y - yy * r, xx = X / r, jj = X - xx * r;
-        const long long deep = (((long long)img * c * r * r + (long long)ch * r * r + ii * r + jj) * h + yy) * w + xx;
-        if (UNSHUFFLE) dst[deep] = src[i];
-        else dst[i] = src[deep];
+    // "big" tensor (N,C,H*r,W*r), "deep" tensor (N,C*r*r,H,W).  grid: (chunks of W, H*r, N*C); a thread owns
+    // column xx of the deep tensor for one big row: r deep planes, each read/written coalesced across the
+    // wave, against r contiguous elements of the big row.
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xx >= w) return;
+    const int Y = blockIdx.y, plane = blockIdx.z;          // plane = img * c + ch
+    const int yy = Y / r, ii = Y - yy * r;
+    const long long hw = (long long)h * w;
+    const long long deep0 = ((long long)plane * r * r + (long long)ii * r) * hw + (long long)yy * w + xx;
+    const long long big0 = ((long long)plane * h * r + Y) * ((long long)w * r) + (long long)xx * r;
+    (void)c;
+    if (vec && r == 4 && sizeof(T) == 4) {  // vec: the big tensor is 16-byte aligned
+        if (UNSHUFFLE) {
+            const uint4 v = *(const uint4*)(src + big0);
+            dst[deep0] = (T)v.x; dst[deep0 + hw] = (T)v.y; dst[deep0 + 2 * hw] = (T)v.z; dst[deep0 + 3 * hw] = (T)v.w;
+        } else {
+            *(uint4*)(dst + big0) = make_uint4((unsigned)src[deep0], (unsigned)src[deep0 + hw], (unsigned)src[deep0 + 2 * hw],
+                                               (unsigned)src[deep0 + 3 * hw]);
+        }
+    } else {
+        for (int jj = 0; jj < r; ++jj) {
+            if (UNSHUFFLE) dst[deep0 + jj * hw] = src[big0 + jj];
+            else dst[big0 + jj] = src[deep0 + jj * hw];
+        }
     }
 }
 
 __global__ void pixel_shuffle_nhwc_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst,
-                                                      int n, int c, int h, int w, int r, int cstride)
+                                                      int c, int h, int w, int r, int cstride, int vec)
 {
-    const long long total = (long long)n * c * h * r * w * r;
-    const int wr = w * r, hr = h * r;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int X = (int)(i % wr);
-        long long t = i / wr;
-        const int Y = (int)(t % hr); t /= hr;
-        const int ch = (int)(t % c);
-        const int img = (int)(t / c);
-        const int yy = Y / r, ii = Y - yy * r, xx = X / r, jj = X - xx * r;
-        dst[i] = bf16_bits_to_f32(src[(((long long)img * h + yy) * w + xx) * cstride + ch * r * r + ii * r + jj]);
+    // grid: (chunks of W, H*r, N*C); a thread converts the r channels (ch*r*r + ii*r + 0..r-1) of source pixel
+    // (yy, xx) into r contiguous fp32 of the output row
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xx >= w) return;
+    const int Y = blockIdx.y, plane = blockIdx.z;
+    const int img = plane / c, ch = plane - img * c;
+    const int yy = Y / r, ii = Y - yy * r;
+    const unsigned short* sp = src + (((long long)img * h + yy) * w + xx) * cstride + ch * r * r + ii * r;
+    float* dp = dst + ((long long)plane * h * r + Y) * ((long long)w * r) + (long long)xx * r;
+    if (vec && r == 4) {
+        const uint2 v = *(const uint2*)sp;   // 4 bf16, 8-byte aligned: cstride % 8 == 0 and r == 4
+        *(float4*)dp = make_float4(bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y));
+    } else {
+        for (int jj = 0; jj < r; ++jj) dp[jj] = bf16_bits_to_f32(sp[jj]);
     }
 }
 
 template <typename T>
-__global__ void nearest_down_kernel(const T* __restrict__ src, T* __restrict__ dst, int nc, int h, int w, int ho,
-                                    int wo, float inv)
+__global__ void nearest_down_kernel(const T* __restrict__ src, T* __restrict__ dst, int h, int w, int ho, int wo, float inv)
 {
-    const long long total = (long long)nc * ho * wo;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % wo);
-        long long t = i / wo;
-        const int oy = (int)(t % ho);
-        const long long pl = t / ho;
-        int iy = (int)floorf(__fmul_rn((float)oy, inv)); if (iy > h - 1) iy = h - 1;
-        int ix = (int)floorf(__fmul_rn((float)ox, inv)); if (ix > w - 1) ix = w - 1;
-        dst[i] = src[(pl * h + iy) * w + ix];
-    }
+    // grid: (chunks of an output row, output row, plane)
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ox >= wo) return;
+    const int oy = blockIdx.y;
+    const long long pl = blockIdx.z;
+    int iy = (int)floorf(__fmul_rn((float)oy, inv)); if (iy > h - 1) iy = h - 1;
+    int ix = (int)floorf(__fmul_rn((float)ox, inv)); if (ix > w - 1) ix = w - 1;
+    dst[(pl * ho + oy) * wo + ox] = src[(pl * h + iy) * w + ix];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -654,9 +656,10 @@ SRHIP_API int srhip_upsample_grid_bilinear_nhwc(const void* src, void* dst, int 
 {
     SRHIP_REQUIRE(src && dst, "upsample_nhwc: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && sh >= 1 && sw >= 1 && th >= 1 && tw >= 1, "upsample_nhwc: bad shape");
-    const long long work = (long long)n * th * tw * (c / 8);
-    hipLaunchKernelGGL(upsample_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const unsigned short*)src, (unsigned short*)dst, n, c, sh, sw, th, tw, coord_axis(tw), coord_axis(th));
+    SRHIP_REQUIRE(th <= 65535 && n <= 65535, "upsample_grid_bilinear_nhwc: at most 65535 target rows and images per call");
+    hipLaunchKernelGGL(upsample_nhwc_kernel, dim3(srhip_div_up((long long)tw * (c / 8), kThreads), th, n), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)src, (unsigned short*)dst, c, sh, sw, th, tw, coord_axis(tw),
+                       coord_axis(th));
     return srhip_check_launch("upsample_nhwc");
 }
 
@@ -665,7 +668,8 @@ SRHIP_API int srhip_upsample_grid_bilinear_f32(const float* src, float* dst, int
 {
     SRHIP_REQUIRE(src && dst, "upsample_f32: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && sh >= 1 && sw >= 1 && th >= 1 && tw >= 1, "upsample_f32: bad shape");
-    hipLaunchKernelGGL(sample_f32_kernel<0>, dim3(grid_for((long long)n * th * tw, srhip_num_cus())), dim3(kThreads), 0,
+    SRHIP_REQUIRE(th <= 65535 && n <= 65535, "upsample_f32: at most 65535 target rows and images per call");
+    hipLaunchKernelGGL(sample_f32_kernel<0>, dim3(srhip_div_up(tw, kThreads), th, n), dim3(kThreads), 0,
                        (hipStream_t)stream, src, (const float*)nullptr, dst, n, c, sh, sw, th, tw, (int)SRHIP_BILINEAR, 0,
                        coord_axis(tw), coord_axis(th));
     return srhip_check_launch("upsample_f32");
@@ -693,7 +697,8 @@ SRHIP_API int srhip_backward_warp_f32(const float* frame, const float* motion, f
     SRHIP_REQUIRE(frame && motion && dst, "backward_warp_f32: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 2 && w >= 2, "backward_warp_f32: bad shape (h, w must be >= 2)");
     SRHIP_REQUIRE(mode == SRHIP_BILINEAR || mode == SRHIP_NEAREST, "backward_warp_f32: bad mode %d", mode);
-    hipLaunchKernelGGL(sample_f32_kernel<1>, dim3(grid_for((long long)n * h * w, srhip_num_cus())), dim3(kThreads), 0,
+    SRHIP_REQUIRE(h <= 65535 && n <= 65535, "backward_warp_f32: at most 65535 rows and images per call");
+    hipLaunchKernelGGL(sample_f32_kernel<1>, dim3(srhip_div_up(w, kThreads), h, n), dim3(kThreads), 0,
                        (hipStream_t)stream, frame, motion, dst, n, c, h, w, h, w, mode, align_corners ? 1 : 0, CoordAxis{0, 0},
                        CoordAxis{0, 0});
     return srhip_check_launch("backward_warp_f32");
@@ -705,8 +710,9 @@ SRHIP_API int srhip_backward_warp_nhwc(const void* frame, const float* motion, v
     SRHIP_REQUIRE(frame && motion && dst, "backward_warp_nhwc: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && h >= 2 && w >= 2, "backward_warp_nhwc: bad shape");
     SRHIP_REQUIRE(mode == SRHIP_BILINEAR || mode == SRHIP_NEAREST, "backward_warp_nhwc: bad mode %d", mode);
-    hipLaunchKernelGGL(warp_nhwc_kernel, dim3(grid_for((long long)n * h * w * (c / 8), srhip_num_cus())), dim3(kThreads), 0,
-                       (hipStream_t)stream, (const unsigned short*)frame, motion, (unsigned short*)dst, n, c, h, w, mode,
+    SRHIP_REQUIRE(h <= 65535 && n <= 65535, "backward_warp_nhwc: at most 65535 rows and images per call");
+    hipLaunchKernelGGL(warp_nhwc_kernel, dim3(srhip_div_up((long long)w * (c / 8), kThreads), h, n), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)frame, motion, (unsigned short*)dst, c, h, w, mode,
                        align_corners ? 1 : 0);
     return srhip_check_launch("backward_warp_nhwc");
 }
@@ -732,23 +738,27 @@ SRHIP_API int srhip_pixel_shuffle(const void* src, void* dst, int n, int c, int 
 {
     SRHIP_REQUIRE(src && dst, "pixel_shuffle: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && r >= 1, "pixel_shuffle: bad shape");
-    const int g = grid_for((long long)n * c * h * r * w * r, srhip_num_cus());
+    SRHIP_REQUIRE((long long)h * r <= 65535 && (long long)n * c <= 65535, "pixel_shuffle: at most 65535 output rows and 65535 planes per call");
+    const dim3 grid(srhip_div_up(w, kThreads), h * r, n * c);
+    const int vec = ((size_t)dst % 16 == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    if (elem_size == 4) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned, false>), dim3(g), dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, n, c, h, w, r);
-    else if (elem_size == 2) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned short, false>), dim3(g), dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, n, c, h, w, r);
+    if (elem_size == 4) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned, false>), grid, dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, c, h, w, r, vec);
+    else if (elem_size == 2) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned short, false>), grid, dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, c, h, w, r, vec);
     else { srhip_set_error("pixel_shuffle: elem_size must be 2 or 4"); return SRHIP_ERR_INVALID; }
     return srhip_check_launch("pixel_shuffle");
 }
 
 SRHIP_API int srhip_pixel_unshuffle(const void* src, void* dst, int n, int c, int h, int w, int r, int elem_size,
-                                    void* stream)
+                                  void* stream)
 {
     SRHIP_REQUIRE(src && dst, "pixel_unshuffle: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && r >= 1, "pixel_unshuffle: bad shape");
-    const int g = grid_for((long long)n * c * h * r * w * r, srhip_num_cus());
+    SRHIP_REQUIRE((long long)h * r <= 65535 && (long long)n * c <= 65535, "pixel_unshuffle: at most 65535 output rows and 65535 planes per call");
+    const dim3 grid(srhip_div_up(w, kThreads), h * r, n * c);
+    const int vec = ((size_t)src % 16 == 0) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    if (elem_size == 4) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned, true>), dim3(g), dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, n, c, h, w, r);
-    else if (elem_size == 2) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned short, true>), dim3(g), dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, n, c, h, w, r);
+    if (elem_size == 4) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned, true>), grid, dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, c, h, w, r, vec);
+    else if (elem_size == 2) hipLaunchKernelGGL((pixel_shuffle_kernel<unsigned short, true>), grid, dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, c, h, w, r, vec);
     else { srhip_set_error("pixel_unshuffle: elem_size must be 2 or 4"); return SRHIP_ERR_INVALID; }
     return srhip_check_launch("pixel_unshuffle");
 }
@@ -758,8 +768,10 @@ SRHIP_API int srhip_pixel_shuffle_nhwc_to_nchw_f32(const void* src, float* dst, 
 {
     SRHIP_REQUIRE(src && dst, "pixel_shuffle_nhwc_to_nchw_f32: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && r >= 1 && cstride >= c * r * r, "pixel_shuffle_nhwc_to_nchw_f32: bad shape");
-    hipLaunchKernelGGL(pixel_shuffle_nhwc_to_nchw_f32_kernel, dim3(grid_for((long long)n * c * h * r * w * r, srhip_num_cus())),
-                       dim3(kThreads), 0, (hipStream_t)stream, (const unsigned short*)src, dst, n, c, h, w, r, cstride);
+    SRHIP_REQUIRE((long long)h * r <= 65535 && (long long)n * c <= 65535, "pixel_shuffle_nhwc_to_nchw_f32: at most 65535 output rows and 65535 planes per call");
+    const int vec = ((size_t)src % 8 == 0 && (size_t)dst % 16 == 0 && cstride % 4 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(pixel_shuffle_nhwc_to_nchw_f32_kernel, dim3(srhip_div_up(w, kThreads), h * r, n * c), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)src, dst, c, h, w, r, cstride, vec);
     return srhip_check_launch("pixel_shuffle_nhwc_to_nchw_f32");
 }
 
@@ -769,10 +781,11 @@ SRHIP_API int srhip_nearest_down(const void* src, void* dst, int nc, int h, int 
     SRHIP_REQUIRE(src && dst, "nearest_down: null pointer");
     SRHIP_REQUIRE(nc >= 1 && h >= 1 && w >= 1 && ho >= 1 && wo >= 1 && scale_factor > 0.0, "nearest_down: bad shape");
     const float inv = (float)(1.0 / scale_factor);
-    const int g = grid_for((long long)nc * ho * wo, srhip_num_cus());
+    SRHIP_REQUIRE(ho <= 65535 && nc <= 65535, "nearest_down: at most 65535 output rows and planes per call");
+    const dim3 g(srhip_div_up(wo, kThreads), ho, nc);
     hipStream_t s = (hipStream_t)stream;
-    if (elem_size == 4) hipLaunchKernelGGL(nearest_down_kernel<unsigned>, dim3(g), dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, nc, h, w, ho, wo, inv);
-    else if (elem_size == 2) hipLaunchKernelGGL(nearest_down_kernel<unsigned short>, dim3(g), dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, nc, h, w, ho, wo, inv);
+    if (elem_size == 4) hipLaunchKernelGGL(nearest_down_kernel<unsigned>, g, dim3(kThreads), 0, s, (const unsigned*)src, (unsigned*)dst, h, w, ho, wo, inv);
+    else if (elem_size == 2) hipLaunchKernelGGL(nearest_down_kernel<unsigned short>, g, dim3(kThreads), 0, s, (const unsigned short*)src, (unsigned short*)dst, h, w, ho, wo, inv);
     else { srhip_set_error("nearest_down: elem_size must be 2 or 4"); return SRHIP_ERR_INVALID; }
     return srhip_check_launch("nearest_down");
 }
