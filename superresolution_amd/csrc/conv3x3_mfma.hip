@@ -124,11 +124,10 @@ struct Cfg {
         }
         return clamp63(best);
     }
-    // The residual of row i-1 is consumed at the first micro-step of tap 1 of iteration i: younger are the
-    // rest of iteration i-1 and tap 0 of iteration i ...
-    static constexpr int res_wait() { return clamp63((VM_ROW - 1 - POS_LAST_RES) + vm_in_tap(0)); }
-    // ... and after the row loop (last row) only the rest of its own iteration.
-    static constexpr int res_wait_tail() { return clamp63(VM_ROW - 1 - POS_LAST_RES); }
+    // The residual of row i is waited for at the END of iteration i (behind the last store of the row) and
+    // consumed by the epilogue micro-steps of iteration i+1 or by the drain after the loop: younger than its
+    // last load is only the rest of its own iteration.
+    static constexpr int res_wait() { return clamp63(VM_ROW - 1 - POS_LAST_RES); }
     static_assert(LA >= 4, "the wait-count formulas assume at least 4 rows of look-ahead");
     static_assert(MAXP <= 9 && NRES <= 9, "one LDS-DMA piece and one residual load per tap");
     static constexpr int NFRAG = 9 * KC * NCT;                      // weight fragments per wave
@@ -142,13 +141,13 @@ struct Cfg {
     // wait for everything issued at least MPT - KC - 1 MFMAs ago.
     static constexpr bool SPREAD = MPT >= KC + 2;
     // micro-steps run between the MFMAs of tap t: first the share of the PREVIOUS row's epilogue
-    //   tap 2k+1: [residual wait] + channels 0..3 of store group k;  tap 2k+2: channels 4..7 + pack/store
+    //   tap 2k+1: channels 0..3 of store group k;  tap 2k+2: channels 4..7 + pack/store
     // then this tap's LDS-DMA piece and residual load.
     static constexpr int epi_steps(int t) {
         if (t == 0 || OUT_F32) return 0;
         const int k = (t - 1) / 2;
         if (k >= NST) return 0;
-        return (t & 1) ? 4 + ((k == 0 && HAS_RES) ? 1 : 0) : 5;
+        return (t & 1) ? 4 : 5;
     }
     static constexpr int tap_steps(int t) { return epi_steps(t) + dma_in_tap(t) + res_in_tap(t); }
 };
@@ -255,6 +254,15 @@ __device__ __forceinline__ u32x4 buffer_load_b128_async(const i32x4 srd, unsigne
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voffset), "s"(srd), "s"(soffset));
     return r;
 }
+// 16-byte store whose data registers stay untouched for four more issue cycles.  The store unit reads
+// its 128 bits of data after the instruction has issued; the compiler's hazard table exempts buffer stores
+// that carry an SGPR offset and happily re-uses the first data register in the very next VALU
+// instruction, and with two waves per SIMD that write reaches lanes 12-15 of every 16-lane group before
+// the store has read them (seen as stray LDS addresses in the output).
+__device__ __forceinline__ void buffer_store_b128_guarded(const u32x4 data, const i32x4 srd, unsigned voffset, unsigned soffset)
+{
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(data), "v"(voffset), "s"(srd), "s"(soffset) : "memory");
+}
 constexpr unsigned kOobOffset = 0x80000000u;  // beyond every image: the bounds check drops the lane
 
 template <class C>
@@ -359,6 +367,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
         const unsigned img_out = C::OUT_F32 ? (unsigned)p.cout * plane_bytes : (unsigned)(H * W) * (unsigned)p.cout_stride * 2u;
         const __amdgpu_buffer_rsrc_t dst_rsrc =
             __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)n * img_out, 0, (int)img_out, 0x00020000);
+        const i32x4 dst_srd = make_srd(p.dst + (long long)n * img_out, img_out);
         const i32x4 res_srd = make_srd(C::HAS_RES ? p.res + (long long)n * img_out : p.dst, C::HAS_RES ? img_out : 0u);
         const unsigned out_pitch = (unsigned)W * (unsigned)p.cout_stride * 2u;  // bytes per output row (NHWC)
         const int xpix = x0 + 32 * pg + pl;
@@ -422,14 +431,13 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 
         // ---- micro-steps of the second epilogue half of output row yy (staging -> HBM), whose
         // residual is in resv[AP].  store_soff is the scalar row offset (kOobOffset drops the row).
-        auto epi_res_wait = [&](auto ap_c, auto tail_c) {
+        auto epi_res_wait = [&](auto ap_c) {
             SRHIP_CAPTURE(resv);  // asm operands alone do not make a generic lambda capture
             constexpr int AP = decltype(ap_c)::value;
-            constexpr bool TAIL = decltype(tail_c)::value != 0;
             if constexpr (C::HAS_RES) {
-                vm_wait<TAIL ? C::res_wait_tail() : C::res_wait()>();
+                vm_wait<C::res_wait()>();
 #pragma unroll
-                for (int k = 0; k < C::NRES; ++k) asm volatile("" : "+v"(resv[AP][k]));  // consumers stay behind the wait
+                for (int k = 0; k < C::NRES; ++k) SRHIP_LOAD_FENCE(resv[AP][k]);
             }
         };
         auto epi_read = [&](auto k_c) {  // staging reads of store group k (complete after the next LDS wait)
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
-            __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, vox[k], store_soff, 0);
+            buffer_store_b128_guarded(o, dst_srd, vox[k], store_soff);
         };
 
         // One output row.  PAR = i & 1 selects the fragment buffer that holds tap 0 and the residual set.
@@ -496,6 +504,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                         constexpr int kc = decltype(kc_c)::value;
                         bq[0][kc] = lds_read_b128((rowa[0] + rd[0][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));
                     });
+                    lds_wait<0>();  // landed before this path joins the one that carries the fragments from tap 8
+                    static_for<0, C::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
                 }
             }
 
@@ -512,20 +522,17 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                 constexpr bool EPI = !C::OUT_F32 && t >= 1 && KG < C::NST;
                 if constexpr (C::SPREAD) {
                     lds_wait<0>();
-                    if constexpr (EPI && (t & 1)) asm volatile("" : "+v"(e_lo[KG & 1]), "+v"(e_hi[KG & 1]));
                 } else {
                     if constexpr (EPI && (t & 1)) epi_read(IntC<KG>{});
-                    if (t < 8 || i + 1 < nout) {
-                        static_for<0, C::KC>([&](auto kc_c) {
-                            constexpr int kc = decltype(kc_c)::value;
-                            bq[nxt][kc] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));
-                        });
-                        lds_wait<C::KC>();
-                    } else {
-                        lds_wait<0>();
-                    }
-                    if constexpr (EPI && (t & 1)) asm volatile("" : "+v"(e_lo[KG & 1]), "+v"(e_hi[KG & 1]));  // consumers stay behind the wait
+                    static_for<0, C::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[nxt][kc] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kc)]) ^ (unsigned)(C::kcl_of(kc) << 5));
+                    });
+                    lds_wait<C::KC>();
                 }
+                // everything issued before this tap's own reads has landed: staging read-back, pixel fragments
+                if constexpr (EPI && (t & 1)) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
+                static_for<0, C::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
 
                 constexpr int NS = C::tap_steps(t);
                 static_for<0, C::MPT>([&](auto m_c) {
@@ -540,8 +547,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                         if constexpr (ml == 0 && !C::OUT_F32 && (t % 2 == 0) && (t / 2 < C::NST)) epi_read(IntC<t / 2 + 0 * ml>{});  // + 0 * ml: dependent, so the dead branch is not instantiated
                         if constexpr (ml >= 1 && ml <= C::KC) {
                             constexpr int kr = ml - 1;
-                            if (t < 8 || i + 1 < nout)
-                                bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kr)]) ^ (unsigned)(C::kcl_of(kr) << 5));
+                            bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kr)]) ^ (unsigned)(C::kcl_of(kr) << 5));
                         }
                     }
                     // micro-steps [ml*NS/MPT, (ml+1)*NS/MPT) of this tap
@@ -552,9 +558,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                         if constexpr (S < E) {
                             constexpr int KD = KG + 0 * S;  // dependent on S: dead branches are not instantiated
                             if constexpr (t & 1) {
-                                constexpr int W0 = (KD == 0 && C::HAS_RES) ? 1 : 0;
-                                if constexpr (S < W0) epi_res_wait(IntC<PAR ^ 1>{}, IntC<0>{});
-                                else epi_elem(IntC<KD>{}, IntC<S - W0>{}, IntC<PAR ^ 1>{});
+                                epi_elem(IntC<KD>{}, IntC<S + 0 * KD>{}, IntC<PAR ^ 1>{});
                             } else {
                                 if constexpr (S < 4) epi_elem(IntC<KD>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
                                 else epi_store(IntC<KD>{}, st_soff);
@@ -583,6 +587,15 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                     constexpr int ct = S / 4, g = S % 4;
                     lds_write_acc_quad<ct, g>(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);
                 });
+                // Tap 8 fetched the fragments of the next row's tap 0 (older than the staging writes above).
+                // No asm load stays in flight across the end of a row: where the two row parities' paths
+                // merge the compiler moves registers, and it does not know that these are still being written.
+                lds_wait<4 * C::NCT>();
+                static_for<0, C::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
+                // The row's residual must have landed before anything consumes it (next iteration or the drain
+                // after the loop).  Waiting HERE, in the code of this row parity, keeps the wait in front of the
+                // register moves the compiler places where the two parities' paths merge.
+                epi_res_wait(IntC<PAR>{});
             } else {
                 // fp32 NCHW output (network output / fp32-accumulate checks): plain epilogue.
                 const unsigned pixoff = (unsigned)((y * W + xpix) * 4);
@@ -596,6 +609,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                         const unsigned vo = (xpix < W && co < p.cout) ? (unsigned)co * plane_bytes + pixoff : kOobOffset;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst_rsrc, vo, 0, 0);
                     }
+                lds_wait<0>();  // tap 8's fetch of the next row's tap 0: nothing stays in flight across rows
+                static_for<0, C::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
             }
         };
 
@@ -618,11 +633,11 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             // drain: second epilogue half of the last row
             const unsigned st_soff = (unsigned)(y1 - 1) * out_pitch;
             auto tail = [&](auto ap_c) {
-                epi_res_wait(ap_c, IntC<1>{});
                 static_for<0, C::NST>([&](auto k_c) {
                     epi_read(k_c);
                     lds_wait<0>();
-                    asm volatile("" : "+v"(e_lo[decltype(k_c)::value & 1]), "+v"(e_hi[decltype(k_c)::value & 1]));
+                    SRHIP_LOAD_FENCE(e_lo[decltype(k_c)::value & 1]);
+                    SRHIP_LOAD_FENCE(e_hi[decltype(k_c)::value & 1]);
                     static_for<0, 8>([&](auto e_c) { epi_elem(k_c, e_c, ap_c); });
                     epi_store(k_c, st_soff);
                 });

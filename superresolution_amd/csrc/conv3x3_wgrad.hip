@@ -296,9 +296,10 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                 }
                 if constexpr (st == 0) {
 #pragma unroll
-                    for (int k = 0; k < C::NKS; ++k) asm volatile("" : "+v"(alo[k]), "+v"(ahi[k]));
+                    for (int k = 0; k < C::NKS; ++k) { SRHIP_LOAD_FENCE(alo[k]); SRHIP_LOAD_FENCE(ahi[k]); }
                 }
-                asm volatile("" : "+v"(blo[cur]), "+v"(bhi[cur]));  // consumers stay behind the wait
+                SRHIP_LOAD_FENCE(blo[cur]);  // consumers stay behind the wait
+                SRHIP_LOAD_FENCE(bhi[cur]);
                 const bf16x8 a = join(alo[s], ahi[s]);
                 const bf16x8 b = join(blo[cur], bhi[cur]);
                 wg_mfma<t>(acc[t], a, b);

@@ -48,3 +48,10 @@ int srhip_num_cus();
     } while (0)
 
 static inline int srhip_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+// Results of asm loads are invisible to the compiler's wait bookkeeping: it believes the destination
+// registers hold data as soon as the load has issued and may copy them (register moves at loop exits and
+// merges) before the hand-placed wait.  Every such value therefore passes through one fence right after
+// the wait that covers it; the marker names the registers in the assembly, and tools/isa_lint.py checks
+// that nothing touches them between the load and this marker on any path.
+#define SRHIP_LOAD_FENCE(x) asm volatile("; srhip-fence %0" : "+v"(x))
+
