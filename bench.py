@@ -208,7 +208,8 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
         opt.step()
         return loss
 
-    for _ in range(warmup):
+    loss0 = float(step().detach())
+    for _ in range(max(warmup - 1, 0)):
         step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -226,7 +227,10 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert bool(torch.isfinite(loss))
+    # a step timed on NaN tensors runs at different clocks: the loss must be finite and must have fallen on
+    # this fixed batch, and every gradient of the last step must be finite
+    assert bool(torch.isfinite(loss)) and float(loss.detach()) < loss0, f"training diverged: {loss0} -> {float(loss.detach())}"
+    assert bool(torch.isfinite(red.flat).all()), "non-finite gradients"
     # every rank runs the instrumented extra steps: they contain the gradient all-reduce
     k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, S, 2)
     if rank != 0:
@@ -290,6 +294,7 @@ def main():
     def step():
         return model.infer(lr[:, -1], hb[:, -1])
 
+    first = step().clone()  # the timed frames must reproduce it bit for bit (same inputs)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -308,7 +313,10 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # a number measured on garbage is worthless: finite, of sane magnitude, and identical to the first pass
     assert out.shape == (1, 3, HR_H, HR_W) and bool(torch.isfinite(out).all())
+    assert float(out.abs().max()) < 1e3 and torch.equal(out, first), "inference output is not reproducible"
+    del first
 
     # every rank takes part in the instrumented passes and in the training leg (gradient all-reduce)
     k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, HR_H, 5)

@@ -40,7 +40,8 @@ struct LossParams {
     Gauss g;
 };
 
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// torch.clamp semantics: a NaN stays a NaN (fminf/fmaxf alone would return the bound and hide it)
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
 
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(const LossParams p)
 {

@@ -21,8 +21,13 @@ def timeit(fn, iters=10):
     return ts[len(ts) // 2], ts[0]
 
 
+_SPARSE = False
+
+
 def case(name, ca, cb, cout, res=False, f32=False, act=1, alpha=1.0, h=H, w=W, n=1):
     xa = (torch.rand(n, h, w, ca, device=dev) - 0.5).to(torch.bfloat16)
+    if _SPARSE:
+        xa = torch.relu(xa)
     xb = (torch.rand(n, h, w, cb, device=dev) - 0.5).to(torch.bfloat16) if cb else None
     wt = torch.randn(cout, ca + cb, 3, 3, device=dev) * 0.05
     b = torch.randn(cout, device=dev) * 0.1
@@ -40,6 +45,28 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         case("64->64 relu", 64, 0, 64)
         case("64->64 relu 16x1024^2", 64, 0, 64, h=1024, w=1024, n=16)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "res":
+        case("64->64 relu 16x1024^2", 64, 0, 64, h=1024, w=1024, n=16)
+        case("64->64 +res 16x1024^2", 64, 0, 64, res=True, act=0, alpha=0.2, h=1024, w=1024, n=16)
+        case("64->64 +res 4K", 64, 0, 64, res=True, act=0, alpha=0.2)
+        case("16->64 relu 4K", 16, 0, 64)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sparse":
+        # ReLU-like operands (half the values exactly zero): the chip draws less power than on dense random
+        # data and the clocks stay up, as in the real network
+        def sparse_case(name, **kw):
+            global _SPARSE
+            _SPARSE = True
+            case(name, 64, 0, 64, **kw)
+            _SPARSE = False
+        sparse_case("64->64 relu 16x1024^2 sparse", h=1024, w=1024, n=16)
+        sparse_case("64->64 relu 4K sparse")
+        x = torch.relu(torch.rand(16, 1024, 1024, 64, device=dev) - 0.5).to(torch.bfloat16)
+        dz = torch.relu(torch.rand(16, 1024, 1024, 64, device=dev) - 0.5).to(torch.bfloat16)
+        dw = torch.empty(64, 64, 3, 3, device=dev); db = torch.empty(64, device=dev)
+        med, best = timeit(lambda: F_.conv3x3_wgrad(x, dz, dw, db, 64, 64))
+        print(f"wgrad 64x64 sparse median {med:7.3f} ms best {best:7.3f} ms", flush=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bands":
         for hh in (2160, 1080, 540, 360, 216, 108, 54, 27):
@@ -72,7 +99,7 @@ def wgrad_case(name, ci, co, h=1024, w=1024, n=16):
     print(f"wgrad {name:22s} median {med:7.3f} ms  best {best:7.3f} ms  {flop / med / 1e9:8.1f} TFLOP/s  {byts / med / 1e6:7.1f} GB/s", flush=True)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("quick", "one", "bands")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("quick", "one", "bands", "res", "sparse")):
     wgrad_case("64x64 16x1024^2", 64, 64)
     wgrad_case("32x64 16x1024^2", 32, 64)
     wgrad_case("16x64 16x1024^2", 16, 64)
