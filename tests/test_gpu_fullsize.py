@@ -114,3 +114,88 @@ def test_training_step_at_bench_size_stays_finite_and_learns():
     assert all(np.isfinite(losses)) and losses[2] < losses[1] < losses[0]
     _, g1 = run(1)
     assert torch.equal(g0, g1)
+
+
+def _crop_check(F_, x, run, windows, n_check=(0,), xb=None, res=None, nchw=False):
+    """`run(x, xb, res)` on the full tensors and on windows with a one-pixel halo: interiors must be bit-equal."""
+    full = run(x, xb, res)
+    n, hh, ww = x.shape[:3]
+    for img in n_check:
+        for (y0, y1, x0, x1) in windows:
+            ya, yb, xa, xe = max(y0 - 1, 0), min(y1 + 1, hh), max(x0 - 1, 0), min(x1 + 1, ww)
+            cut = lambda t: None if t is None else t[img:img + 1, ya:yb, xa:xe].contiguous()
+            crop = run(cut(x), cut(xb), cut(res))
+            iy0, ix0 = y0 - ya, x0 - xa
+            if nchw:
+                a, b = crop[:, :, iy0:iy0 + (y1 - y0), ix0:ix0 + (x1 - x0)], full[img:img + 1, :, y0:y1, x0:x1]
+            else:
+                a, b = crop[:, iy0:iy0 + (y1 - y0), ix0:ix0 + (x1 - x0)], full[img:img + 1, y0:y1, x0:x1]
+            assert torch.equal(a, b), f"image {img} window {(y0, y1, x0, x1)}"
+
+
+@pytest.mark.parametrize("case", ["res_add", "res_mask", "concat", "c16", "to3_f32", "c48", "c32"])
+def test_conv3x3_variants_training_size_crop_consistency(F_, case):
+    """Every kernel configuration the two networks use, at the training batch (16 x 1024 x 1024, several work
+    items per workgroup) : windows of any image equal the same layer run on the window alone, bit for bit.
+    Catches races that only appear under full memory load (they never showed in the small parity cases)."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    n, s = 16, 1024
+    cfg = {"res_add": (64, 0, 64), "res_mask": (64, 0, 64), "concat": (32, 64, 64), "c16": (16, 0, 64),
+           "to3_f32": (64, 0, 3), "c48": (48, 0, 48), "c32": (32, 0, 32)}[case]
+    ca, cb, cout = cfg
+    x = torch.relu(torch.rand(n, s, s, ca, device="cuda", generator=g) - 0.3).to(torch.bfloat16)
+    xb = torch.relu(torch.rand(n, s, s, cb, device="cuda", generator=g) - 0.3).to(torch.bfloat16) if cb else None
+    w = torch.randn(cout, ca + cb, 3, 3, device="cuda", generator=g) * 0.05
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    wp = F_.conv3x3_pack_weights(w, ca, ca, cb, cb)
+    res = None
+    if case in ("res_add", "res_mask"):
+        res = (torch.rand(n, s, s, 64, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    kw = dict(act=F_.ACT_RELU)
+    if case == "res_add":
+        kw = dict(act=F_.ACT_NONE, alpha=0.2, res_mode=F_.RES_ADD)
+    if case == "res_mask":
+        kw = dict(act=F_.ACT_NONE, res_mode=F_.RES_MASK)
+    if case == "to3_f32":
+        kw = dict(act=F_.ACT_NONE, out_nchw_f32=True)
+    run = lambda x_, xb_, r_: F_.conv3x3(x_, wp, b, cout, src_b=xb_, res=r_, **kw)
+    windows = [(0, 30, 0, 140), (500, 540, 300, 600), (990, 1024, 900, 1024), (255, 258, 127, 130)]
+    _crop_check(F_, x, run, windows, n_check=(0, 7, 15), xb=xb, res=res, nchw=(case == "to3_f32"))
+    # and the launch repeats bit for bit
+    assert torch.equal(run(x, xb, res), run(x, xb, res))
+
+
+def test_wgrad_training_size_partition_and_determinism(F_):
+    """Weight / bias gradient at 16 x 1024 x 1024: repeats bit for bit, and equals the sum over four batch
+    quarters (accumulate form) up to fp32 summation order."""
+    g = torch.Generator(device="cuda").manual_seed(23)
+    n, s = 16, 1024
+    x = torch.relu(torch.rand(n, s, s, 64, device="cuda", generator=g) - 0.4).to(torch.bfloat16)
+    dz = ((torch.rand(n, s, s, 64, device="cuda", generator=g) - 0.5) * 1e-2).to(torch.bfloat16)
+    dw, db = torch.empty(64, 64, 3, 3, device="cuda"), torch.empty(64, device="cuda")
+    F_.conv3x3_wgrad(x, dz, dw, db, 64, 64)
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    F_.conv3x3_wgrad(x, dz, dw2, db2, 64, 64)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    pw, pb = torch.zeros_like(dw), torch.zeros_like(db)
+    for q in range(4):
+        F_.conv3x3_wgrad(x[4 * q:4 * q + 4], dz[4 * q:4 * q + 4], pw, pb, 64, 64, accumulate=True)
+    assert bool(torch.isfinite(dw).all())
+    assert (pw - dw).abs().max().item() <= 1e-4 * dw.abs().max().item()
+    assert (pb - db).abs().max().item() <= 1e-4 * db.abs().max().item()
+
+
+def test_reprfn_full_size_determinism_and_batching():
+    """RepRFN (configs/trainer/4x_RepRFN.yaml) at 270x480 -> 1080x1920: finite, repeats bit for bit, and a batch
+    of two equals the frames run one at a time (its 48-channel layers run two waves per SIMD)."""
+    from superresolution_amd import RepRFN
+    torch.manual_seed(42)
+    m = RepRFN().cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 270, 480, generator=g).cuda()
+    with torch.no_grad():
+        y = m.infer(x)
+        assert y.shape == (2, 3, 1080, 1920) and bool(torch.isfinite(y).all()) and float(y.abs().max()) < 1e3
+        assert torch.equal(y, m.infer(x))
+        for i in range(2):
+            assert torch.equal(m.infer(x[i:i + 1]), y[i:i + 1])
