@@ -37,7 +37,7 @@ typedef enum {
 
 typedef enum { SRHIP_ACT_NONE = 0, SRHIP_ACT_RELU = 1, SRHIP_ACT_LRELU = 2 } srhip_act;
 typedef enum { SRHIP_BILINEAR = 0, SRHIP_NEAREST = 1 } srhip_interp;
-typedef enum { SRHIP_RES_ADD = 0, SRHIP_RES_MASK = 1 } srhip_res_mode;
+typedef enum { SRHIP_RES_ADD = 0, SRHIP_RES_MASK = 1, SRHIP_RES_PRE = 2 } srhip_res_mode;
 
 SRHIP_API int srhip_version(void);
 SRHIP_API const char* srhip_last_error(void);
@@ -64,6 +64,7 @@ SRHIP_API int srhip_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, in
  *
  *   dst = alpha * act(conv(concat(src_a, src_b)) + bias) + res          (res_mode ADD)
  *   dst = res > 0 ? alpha * act(conv(...) + bias) : 0                   (res_mode MASK)
+ *   dst = act(alpha * (conv(...) + bias) + res)                         (res_mode PRE)
  *
  * The MASK form is the backward of conv -> ReLU chains: with transpose_flip
  * weights the convolution yields dL/dx of the NEXT layer and `res` is the saved

@@ -60,6 +60,7 @@ struct Cfg {
     static constexpr bool OUT_F32 = OUT_F32_;   // epilogue writes fp32 NCHW instead of bf16 NHWC
     static constexpr bool HAS_RES = RES_ != 0;  // the epilogue reads a second tensor `res` (bf16 NHWC only):
     static constexpr bool RES_MASK = RES_ == 2; // 1: dst += res;  2: dst = res > 0 ? dst : 0 (ReLU backward)
+    static constexpr bool RES_PRE = RES_ == 3;  // 3: res joins the sum BEFORE the activation (partial sums of wide layers)
     static constexpr int KC = KC_;              // 16-channel K planes
     static constexpr int CT_TOTAL = CT_TOTAL_;  // 32-wide output-channel tiles of the layer
     static constexpr int CSPLIT = CSPLIT_;      // waves that share a pixel group (split over cout tiles)
@@ -450,14 +451,16 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             constexpr int e = decltype(e_c)::value;
             constexpr int AP = decltype(ap_c)::value;
             const float x = e < 4 ? e_lo[k & 1][e & 3] : e_hi[k & 1][e & 3];
-            const float t = fmaf(x, p.alpha, breg[e]);
-            float v = fmaxf(t, t * p.slope);  // act(t) = max(t, slope * t), slope in {1, 0, s}
+            float t = fmaf(x, p.alpha, breg[e]);
+            float rv = 0.0f;
             if constexpr (C::HAS_RES) {
                 const unsigned rr = resv[AP][k][e >> 1];
-                const float rv = (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
-                if constexpr (C::RES_MASK) v = rv > 0.0f ? v : 0.0f;
-                else v += rv;
+                rv = (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
             }
+            if constexpr (C::RES_PRE) t += rv;
+            float v = fmaxf(t, t * p.slope);  // act(t) = max(t, slope * t), slope in {1, 0, s}
+            if constexpr (C::RES_MASK) v = rv > 0.0f ? v : 0.0f;
+            else if constexpr (C::HAS_RES && !C::RES_PRE) v += rv;
             ev[e] = v;
         };
         auto epi_store = [&](auto k_c, const unsigned store_soff) {
@@ -798,12 +801,13 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     if (a->cb != 0) SRHIP_REQUIRE(a->ca == 32 && a->cb == 64, "conv3x3: the only two-source form is concat(32 ch, 64 ch), got %d + %d", a->ca, a->cb);
     else SRHIP_REQUIRE(a->ca <= 64, "conv3x3: a single source carries at most 64 channels (got %d)", a->ca);
     SRHIP_REQUIRE(a->alpha > 0.0f, "conv3x3: alpha must be positive");
-    SRHIP_REQUIRE(a->res_mode == SRHIP_RES_ADD || a->res_mode == SRHIP_RES_MASK, "conv3x3: bad res_mode %d", a->res_mode);
+    SRHIP_REQUIRE(a->res_mode == SRHIP_RES_ADD || a->res_mode == SRHIP_RES_MASK || a->res_mode == SRHIP_RES_PRE, "conv3x3: bad res_mode %d", a->res_mode);
     hipStream_t s = (hipStream_t)stream;
 #define SRHIP_CONV_CASE(KC, CT, CSPLIT)                                                                 \
     if (kc == KC && ct == CT) {                                                                         \
         if (a->dst_nchw_f32) return launch_conv<Cfg<KC, CT, CSPLIT, true, 0>>(p, s);                    \
         if (a->res != nullptr && a->res_mode == SRHIP_RES_MASK) return launch_conv<Cfg<KC, CT, CSPLIT, false, 2>>(p, s); \
+        if (a->res != nullptr && a->res_mode == SRHIP_RES_PRE) return launch_conv<Cfg<KC, CT, CSPLIT, false, 3>>(p, s); \
         if (a->res != nullptr) return launch_conv<Cfg<KC, CT, CSPLIT, false, 1>>(p, s);                 \
         return launch_conv<Cfg<KC, CT, CSPLIT, false, 0>>(p, s);                                        \
     }

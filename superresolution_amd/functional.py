@@ -11,7 +11,7 @@ import torch
 from ._lib import Conv3x3Args, check, lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-RES_ADD, RES_MASK = 0, 1
+RES_ADD, RES_MASK, RES_PRE = 0, 1, 2
 _MODES = {"bilinear": 0, "nearest": 1}
 
 
@@ -81,7 +81,8 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
             cout_stride: Optional[int] = None, out: Optional[torch.Tensor] = None,
             res_mode: int = RES_ADD) -> torch.Tensor:
     """dst = alpha * act(conv3x3(concat(src_a, src_b)) + bias) + res   (NHWC bf16 activations);
-    with ``res_mode=RES_MASK``: dst = res > 0 ? alpha * act(...) : 0."""
+    with ``res_mode=RES_MASK``: dst = res > 0 ? alpha * act(...) : 0;
+    with ``res_mode=RES_PRE``: dst = act(alpha * (conv + bias) + res) (partial sums of layers wider than one launch)."""
     src_a = _req(src_a, torch.bfloat16, "src_a")
     n, h, w, ca = src_a.shape
     cb = 0
@@ -206,24 +207,100 @@ def gradient_map(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     return out
 
 
+_pack_cache = {}
+
+
+def _cached_pack(weight: torch.Tensor, tag, build) -> torch.Tensor:
+    """Packed weights of a long-lived weight tensor (a Parameter): rebuilt when the tensor object, its data
+    or its version changes.  The entry dies with the tensor (weak reference), so a new tensor that happens to
+    land on the same address can never hit a stale pack."""
+    import weakref
+    key = (id(weight), tag)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2]
+    packed = build()
+    try:
+        ref = weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None))
+    except TypeError:
+        return packed
+    _pack_cache[key] = (ref, (weight._version, weight.data_ptr()), packed)
+    return packed
+
+
+def _k_slices(cpad: int):
+    """Input-channel slices of at most 64 channels (one MFMA source each)."""
+    out, k0 = [], 0
+    while k0 < cpad:
+        k1 = min(k0 + 64, cpad)
+        out.append((k0, k1))
+        k0 = k1
+    return out
+
+
 def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 1,
-                act: int = ACT_NONE, slope: float = 0.0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.Conv2d (+activation, +residual) on an NHWC bf16 tensor with any channel count: the 3x3 / stride 1 /
-    pad 1 layers whose input fits one MFMA source (<= 64 padded channels) run on the MFMA kernel, in slices of
-    64 output channels; everything else (1x1, strided, wider inputs) runs on the direct kernel.
-    x carries pad16(cin) channels; the result carries pad16(cout)."""
+                act: int = ACT_NONE, slope: float = 0.0, res: Optional[torch.Tensor] = None,
+                alpha: float = 1.0) -> torch.Tensor:
+    """alpha * act(nn.Conv2d(x)) + res on an NHWC bf16 tensor with any channel count, on the MFMA kernel
+    wherever the layer can be written as 3x3 / stride 1 / pad 1 launches:
+
+    * more than 64 input channels: one launch per 64-channel slice, the partial sums chained through the
+      residual input (pre-activation form on the last slice; partial sums are rounded to bf16 between launches);
+    * more than 64 output channels: one launch per 64 output channels, joined by the concat kernel;
+    * 3x3 / stride 2 / pad 1: the stride-1 layer followed by a 2x2 pick of its even pixels (same arithmetic per
+      output pixel, 4x the MFMA work, still far cheaper than the vector-ALU kernel);
+    * 1x1 / pad 0: the weight sits in the centre tap of a 3x3 kernel of zeros.
+
+    Everything else (other kernel sizes, stride 2 without padding, ...) runs on the direct kernel.
+    x carries pad16(cin) channels; the result carries pad16(cout).  `weight` / `bias` may be Parameters: their
+    packed forms are cached per tensor object."""
     cout, cin, kh, kw = weight.shape
-    if (kh, kw, stride, padding) == (3, 3, 1, 1) and x.shape[-1] <= 64 and (cout <= 64 or cout % 64 == 0) and (res is None or cout <= 64):
-        if cout <= 64:
-            wp = conv3x3_pack_weights(weight, cin, x.shape[-1])
-            return conv3x3(x, wp, bias, cout, res=res, act=act, slope=slope)
-        out = None
-        for off in range(0, cout, 64):
-            wp = conv3x3_pack_weights(weight, cin, x.shape[-1], cout=64, cout_off=off)
-            part = conv3x3(x, wp, None if bias is None else bias[off:off + 64].contiguous(), 64, act=act, slope=slope)
-            out = part if out is None else concat_nhwc(out, part)
-        return out
-    return conv2d_direct(x, weight, bias, cin, stride=stride, padding=padding, res=res, act=act, slope=slope)
+    cpad = x.shape[-1]
+    as3x3 = (kh, kw, padding) == (3, 3, 1) and stride in (1, 2)
+    as1x1 = (kh, kw, padding, stride) == (1, 1, 0, 1)
+    if not (as3x3 or as1x1) or (alpha != 1.0 and (cpad > 64 or cout > 64 or stride != 1)):
+        return conv2d_direct(x, weight.detach(), None if bias is None else bias.detach(), cin, stride=stride,
+                             padding=padding, res=res, act=act, slope=slope, alpha=alpha)
+    wd = weight.detach()
+    bd = None if bias is None else bias.detach()
+    slices = _k_slices(cpad)
+    xs = [x] if len(slices) == 1 else [x[..., k0:k1].contiguous() for (k0, k1) in slices]
+
+    def packed(k0, k1, off, n):
+        def build():
+            w = wd[:, k0:min(k1, cin)]
+            if as1x1:
+                w3 = torch.zeros((cout, w.shape[1], 3, 3), dtype=torch.float32, device=w.device)
+                w3[:, :, 1, 1] = w[:, :, 0, 0]
+                w = w3
+            return conv3x3_pack_weights(w.float().contiguous(), w.shape[1], k1 - k0, cout=n, cout_off=off)
+        return _cached_pack(weight, (k0, k1, off, n, as1x1), build)
+
+    fuse_res = res is not None and stride == 1 and len(slices) == 1 and cout <= 64
+    outs = []
+    for off in range(0, cout, 64):
+        n = min(64, cout - off)
+        b = None if bd is None else bd[off:off + n].contiguous()
+        part = None
+        for i, (k0, k1) in enumerate(slices):
+            if min(k1, cin) <= k0:
+                break  # only channel padding left
+            last = i == len(slices) - 1 or min(slices[i + 1][1], cin) <= slices[i + 1][0]
+            wp = packed(k0, k1, off, n)
+            if part is None:
+                part = conv3x3(xs[i], wp, b, n, res=res if (fuse_res and last) else None,
+                               act=act if last else ACT_NONE, slope=slope, alpha=alpha)
+            else:
+                part = conv3x3(xs[i], wp, None, n, res=part, res_mode=RES_PRE, act=act if last else ACT_NONE, slope=slope)
+        outs.append(part)
+    out = outs[0]
+    for o in outs[1:]:
+        out = concat_nhwc(out, o)
+    if stride == 2:
+        out = max_pool2d_nhwc(out, 1, 2)  # out[i, j] = stride-1 result at (2i, 2j)
+    if res is not None and not fuse_res:
+        out = add_bf16(out, res)
+    return out
 
 
 def max_pool2d_nhwc(x: torch.Tensor, k: int, s: int) -> torch.Tensor:

@@ -46,8 +46,7 @@ class ConvActivation(nn.Sequential):
 
     def run(self, x: Tensor, res: Tensor = None) -> Tensor:
         c = self[0]
-        return F_.conv2d_auto(x, c.weight.detach(), c.bias.detach(), stride=c.stride[0], padding=c.padding[0],
-                              act=F_.ACT_RELU, res=res)
+        return F_.conv2d_auto(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU, res=res)
 
 
 class TransConvActivation(nn.Sequential):
@@ -108,8 +107,8 @@ class GBuffersEncoder(nn.Module):
             e = m.run(e)
         last = self.conv_enhance[-1][0]
         # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
-        return F_.conv2d_direct(e, last.weight.detach(), last.bias.detach(), last.in_channels, act=F_.ACT_RELU,
-                                alpha=float(self.enhance_param), res=fmap)
+        return F_.conv2d_auto(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU,
+                              alpha=float(self.enhance_param), res=fmap)
 
 
 class HistoryRefiner(nn.Module):
@@ -333,7 +332,7 @@ class SuperSampler(nn.Module):
 
         fmap = self.main_network.run(fmap_current, fmap_history, fmap_bf, hr_buffer)
         c0, c2 = self.conv_out[0], self.conv_out[2]
-        t = F_.conv2d_auto(F_.concat_nhwc(fmap, fmap_shadow), c0.weight.detach(), c0.bias.detach())
+        t = F_.conv2d_auto(F_.concat_nhwc(fmap, fmap_shadow), c0.weight, c0.bias)
         hr = F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale)
         wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)
         sr_frame = F_.conv3x3(F_.nchw_f32_to_nhwc_bf16(hr), wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)

@@ -1,0 +1,77 @@
+"""conv2d_auto: layers wider than one MFMA launch, stride-2 and 1x1 layers composed from 3x3 / stride-1 MFMA
+launches (core/models/model_final.py:206-452 shapes) against an fp32 convolution of the same bf16-rounded
+operands.  Tolerance 2e-2 (bf16 outputs; partial sums of > 64 input channels are rounded to bf16 between
+launches)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # cin, cout, k, stride, pad, res, act
+    (160, 64, 3, 1, 1, False, 1),
+    (64, 160, 3, 1, 1, False, 1),
+    (112, 64, 1, 1, 0, False, 1),
+    (160, 160, 1, 1, 0, False, 1),
+    (32, 48, 3, 2, 1, False, 1),
+    (192, 256, 3, 2, 1, False, 1),
+    (128, 64, 3, 1, 1, True, 1),
+    (96, 48, 3, 1, 1, False, 0),
+    (384, 128, 3, 1, 1, False, 1),
+    (24, 24, 3, 1, 1, True, 1),
+    (3, 24, 3, 1, 1, False, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,use_res,act", CASES)
+def test_conv2d_auto_matches_fp32_reference(cin, cout, k, stride, pad, use_res, act):
+    from superresolution_amd import functional as F_
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k)
+    n, h, w = 2, 38, 52
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.3)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.5 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    xb = x.to(torch.bfloat16).float()
+    ref = torch.nn.functional.conv2d(xb, wt.to(torch.bfloat16).float(), b, stride=stride, padding=pad)
+    if act == 1:
+        ref = torch.relu(ref)
+    res = None
+    if use_res:
+        res = (torch.rand(ref.shape, generator=g) - 0.5).to(torch.bfloat16)
+        ref = ref + res.float()
+    xn = F_.nchw_f32_to_nhwc_bf16(x.cuda())
+    wp, bp = torch.nn.Parameter(wt.cuda()), torch.nn.Parameter(b.cuda())
+    resn = None if res is None else F_.nchw_f32_to_nhwc_bf16(res.float().cuda())
+    for _ in range(2):  # second call hits the pack cache
+        y = F_.conv2d_auto(xn, wp, bp, stride=stride, padding=pad, act=act, res=resn)
+        assert y.shape == (n, ref.shape[2], ref.shape[3], F_.pad16(cout))
+        got = y[..., :cout].permute(0, 3, 1, 2).float().cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-2, err
+        if F_.pad16(cout) != cout:
+            assert float(y[..., cout:].abs().max()) == 0.0
+    # the cache follows the data: an in-place weight update must be seen
+    with torch.no_grad():
+        wp.mul_(0.5)
+    y2 = F_.conv2d_auto(xn, wp, bp, stride=stride, padding=pad, act=0)
+    ref2 = torch.nn.functional.conv2d(xb, (wt * 0.5).to(torch.bfloat16).float(), b, stride=stride, padding=pad)
+    assert (y2[..., :cout].permute(0, 3, 1, 2).float().cpu() - ref2).abs().max().item() <= 2e-2
+
+
+def test_res_pre_mode_against_oracle():
+    """dst = relu(conv + bias + res): the epilogue form that closes a chain of partial sums."""
+    import numpy as np
+    from oracle import oracle as orc
+    from superresolution_amd import functional as F_
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(1, 64, 20, 70, generator=g) - 0.4)
+    wt = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g) * 0.1
+    r = (torch.rand(1, 64, 20, 70, generator=g) - 0.5).to(torch.bfloat16).float()
+    xb = x.to(torch.bfloat16).float()
+    pre = orc.conv2d(xb.numpy(), wt.to(torch.bfloat16).float().numpy(), b.numpy(), 1, 1) + r.numpy()
+    ref = np.maximum(pre, 0.0)
+    xn = F_.nchw_f32_to_nhwc_bf16(x.cuda())
+    rn = F_.nchw_f32_to_nhwc_bf16(r.cuda())
+    y = F_.conv3x3(xn, F_.conv3x3_pack_weights(wt.cuda(), 64, 64), b.cuda(), 64, res=rn, act=F_.ACT_RELU, res_mode=F_.RES_PRE)
+    assert np.abs(y.permute(0, 3, 1, 2).float().cpu().numpy() - ref).max() <= 2e-2
