@@ -140,13 +140,14 @@ class ESA(nn.Module):
         """x (N,H,W,n_feats) bf16 -> x * sigmoid(conv4(resize(conv3(maxpool(conv2(c1)))) + conv_f(c1))), c1 = conv1(x)."""
         f = self.conv1.out_channels
         h, w = x.shape[1:3]
-        c1_ = F_.conv2d_direct(x, self.conv1.weight.detach(), self.conv1.bias.detach(), n_feats)
+        c1_ = F_.conv2d_auto(x, self.conv1.weight, self.conv1.bias, stride=1, padding=0)      # 1x1 on the MFMA kernel
         c1 = F_.conv2d_direct(c1_, self.conv2.weight.detach(), self.conv2.bias.detach(), f, stride=2, padding=0)
         v_max = F_.max_pool2d_nhwc(c1, 7, 3)
         c3 = F_.conv2d_direct(v_max, self.conv3.weight.detach(), self.conv3.bias.detach(), f, stride=1, padding=1)
-        cf = F_.conv2d_direct(c1_, self.conv_f.weight.detach(), self.conv_f.bias.detach(), f)
+        cf = F_.conv2d_auto(c1_, self.conv_f.weight, self.conv_f.bias, stride=1, padding=0)
         s = F_.resize_bilinear_nhwc(c3, h, w, addend=cf)
-        c4 = F_.conv2d_direct(s, self.conv4.weight.detach(), self.conv4.bias.detach(), f, cout_stride=x.shape[-1])
+        c4 = F_.conv2d_auto(s, self.conv4.weight, self.conv4.bias, stride=1, padding=0)
+        assert c4.shape[-1] == x.shape[-1]
         return F_.sigmoid_gate(x, c4)
 
 
