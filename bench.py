@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train"])
+    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "reprfn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg of the default workload")
     ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training leg of the default workload")
@@ -262,6 +262,112 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
     return res
 
 
+class _FlopCounter:
+    """Algorithmic convolution FLOPs of one forward pass, counted at the operator boundary (2 * Cout * Cin * kh * kw
+    per output pixel with the layer's REAL kernel size and stride; the extra work of composed launches is not
+    counted)."""
+
+    def __init__(self):
+        from superresolution_amd import functional as F_
+        self.F, self.flop, self.depth, self.saved = F_, 0.0, 0, {}
+
+    def __enter__(self):
+        F_ = self.F
+
+        def wrap(name, count):
+            fn = getattr(F_, name)
+            self.saved[name] = fn
+
+            def run(*a, **k):
+                self.depth += 1
+                try:
+                    out = fn(*a, **k)
+                finally:
+                    self.depth -= 1
+                if self.depth == 0:
+                    self.flop += count(out, *a, **k)
+                return out
+            setattr(F_, name, run)
+
+        def px(out, nchw=False):
+            return out.shape[0] * (out.shape[2] * out.shape[3] if nchw else out.shape[1] * out.shape[2])
+        wrap("conv2d_auto", lambda out, x, w, *a, **k: 2.0 * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3] * px(out))
+        wrap("conv2d_direct", lambda out, x, w, *a, **k: 2.0 * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3] * px(out))
+        wrap("conv_transpose2x2s2", lambda out, x, w, *a, **k: 2.0 * w.shape[0] * w.shape[1] * px(out))
+        wrap("conv3x3", lambda out, x, wp, b, cout, *a, **k: 18.0 * (x.shape[-1] + (k["src_b"].shape[-1] if k.get("src_b") is not None else 0))
+             * cout * px(out, k.get("out_nchw_f32", False)))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.F, name, fn)
+
+
+def run_aux_infer(args, world, rank, dev, dist):
+    """Frames/s of the other two networks of the path at the 4K output size: RepRFN (core/arch/RepRFN.py, deploy
+    form, 540x960 -> 2160x3840) and the temporal SuperSampler (core/models/model_final.py, n_history 1,
+    544x960 -> 2176x3840: its encoder needs sizes divisible by 16).  Frames are sharded by rank, no collective."""
+    g = torch.Generator().manual_seed(42 + rank)
+    torch.manual_seed(42)
+    if args.workload == "reprfn":
+        from superresolution_amd import RepRFN
+        model = RepRFN().to(dev).eval()
+        for mod in model.modules():
+            if mod is not model and hasattr(mod, "switch_to_deploy"):
+                mod.switch_to_deploy()
+        x = torch.rand(1, 3, LR_H, LR_W, generator=g).to(dev)
+        step = lambda: model.infer(x)
+        out_shape = (1, 3, HR_H, HR_W)
+        what = "RepRFN(3,3,48,4) deploy form, 540x960 -> 2160x3840, batch 1 per GPU, frames sharded by rank"
+    else:
+        from superresolution_amd.temporal import SuperSampler as TemporalSuperSampler
+        model = TemporalSuperSampler(3, 10, 4, 1).to(dev).eval()
+        h, w = 544, 960
+        lr = torch.rand(1, 3, h, w, generator=g).to(dev)
+        hb = torch.rand(1, 10, 4 * h, 4 * w, generator=g).to(dev)
+        lb = torch.rand(1, 10, h, w, generator=g).to(dev)
+        mv = torch.randn(1, 1, 2, h, w, generator=g).to(dev)
+        hf = torch.rand(1, 1, 3, h, w, generator=g).to(dev)
+        hbuf = torch.rand(1, 1, 10, h, w, generator=g).to(dev)
+        step = lambda: model.infer(lr, hb.clone(), lb.clone(), mv, hf, hbuf.clone())[0]  # the depth clamp is in place
+        out_shape = (1, 3, 4 * h, 4 * w)
+        what = ("temporal SuperSampler(3,10,4,1) (model_final.py), 544x960 -> 2176x3840 with one warped history frame, "
+                "batch 1 per GPU, clips sharded by rank")
+    with torch.no_grad():
+        with _FlopCounter() as fc:
+            first = step().clone()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert tuple(out.shape) == out_shape and bool(torch.isfinite(out).all()) and torch.equal(out, first)
+    if rank != 0:
+        return None
+    ms = dt / args.steps * 1e3
+    tflops = fc.flop / 1e12 / (ms * 1e-3)
+    return {"metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs", "value": world * args.steps / dt,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": what, "frames_per_step_per_gpu": 1, "tflop_per_frame": fc.flop / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "whole network (many small launches; the convolutions' algorithmic FLOPs over "
+                         "the wall time of a frame)", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -282,6 +388,14 @@ def main():
 
     if args.workload == "train":
         res = run_train(args, world, rank, dev, dist)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    if args.workload in ("temporal", "reprfn"):
+        res = run_aux_infer(args, world, rank, dev, dist)
         if rank == 0:
             print(json.dumps(res), flush=True)
         if dist is not None:
