@@ -254,6 +254,14 @@ SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t 
 SRHIP_API int srhip_layernorm_cf_f32(const float* x, const float* weight, const float* bias, float* y,
                                      int n, int c, int hw, float eps, void* stream);
 
+/* Backward of the channels-first LayerNorm (autograd of core/arch/CAMixerSR.py:32-37 under loss.backward(),
+ * core/trainer.py:160): dx (N,C,HW), dweight[C], dbias[C] (overwritten; fixed summation order).
+ * workspace: srhip_layernorm_cf_bwd_workspace_bytes(n, c, hw) bytes of device memory. */
+SRHIP_API size_t srhip_layernorm_cf_bwd_workspace_bytes(int n, int c, int hw);
+SRHIP_API int srhip_layernorm_cf_bwd_f32(const float* x, const float* weight, const float* dy, float* dx,
+                                         float* dweight, float* dbias, void* workspace, int n, int c, int hw,
+                                         float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

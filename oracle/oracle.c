@@ -419,6 +419,39 @@ ORC_API void orc_layernorm_cf(const float* x, const float* weight, const float* 
         }
 }
 
+/* Backward of the channels-first LayerNorm (autograd of CAMixerSR.py:32-37):     */
+/*   xh = (x - u) / den, g = dy * w                                              */
+/*   dx = (g - mean_c(g) - xh * mean_c(g * xh)) / den;  dw = sum dy * xh;  db = sum dy */
+ORC_API void orc_layernorm_cf_bwd(const float* x, const float* weight, const float* dy, float* dx,
+                                  float* dweight, float* dbias, int N, int C, int HW, float eps)
+{
+    for (int c = 0; c < C; ++c) { dweight[c] = 0.0f; dbias[c] = 0.0f; }
+    for (int n = 0; n < N; ++n)
+        for (int p = 0; p < HW; ++p) {
+            const float* xp = x + (size_t)n * C * HW + p;
+            const float* gp = dy + (size_t)n * C * HW + p;
+            float* dp = dx + (size_t)n * C * HW + p;
+            double u = 0.0, s = 0.0;
+            for (int c = 0; c < C; ++c) u += xp[(size_t)c * HW];
+            u /= C;
+            for (int c = 0; c < C; ++c) { const double d = xp[(size_t)c * HW] - u; s += d * d; }
+            s /= C;
+            const double den = sqrt(s + (double)eps);
+            double mg = 0.0, mgx = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const double xh = (xp[(size_t)c * HW] - u) / den, g = (double)gp[(size_t)c * HW] * weight[c];
+                mg += g; mgx += g * xh;
+                dweight[c] += (float)(gp[(size_t)c * HW] * xh);
+                dbias[c] += gp[(size_t)c * HW];
+            }
+            mg /= C; mgx /= C;
+            for (int c = 0; c < C; ++c) {
+                const double xh = (xp[(size_t)c * HW] - u) / den, g = (double)gp[(size_t)c * HW] * weight[c];
+                dp[(size_t)c * HW] = (float)((g - mg - xh * mgx) / den);
+            }
+        }
+}
+
 /* ------------------------------------------------------------------------- */
 /* Pieces used only by the RepRFN ESA block (core/arch/RepRFN.py:295-308):      */
 /* max_pool2d(k,s) without padding, bilinear resize align_corners=False.        */

@@ -191,6 +191,16 @@ def layernorm_cf(x, weight, bias, eps=1e-6):
     return y
 
 
+def layernorm_cf_bwd(x, weight, dy, eps=1e-6):
+    """-> (dx, dweight, dbias) of the channels-first LayerNorm."""
+    x, weight, dy = _c(x), _c(weight), _c(dy)
+    N, C, H, W = x.shape
+    dx, dw, db = np.empty_like(x), np.empty_like(weight), np.empty_like(weight)
+    lib().orc_layernorm_cf_bwd(_p(x), _p(weight), _p(dy), _p(dx), _p(dw), _p(db), _i(N), _i(C), _i(H * W),
+                               ctypes.c_float(eps))
+    return dx, dw, db
+
+
 def max_pool2d(x, k, s):
     x = _c(x)
     N, C, H, W = x.shape

@@ -614,9 +614,103 @@ __global__ void layernorm_cf_kernel(const float* __restrict__ x, const float* __
     }
 }
 
+// LayerNorm backward, pass 1: dx, and per pixel the two numbers pass 2 needs (mean, 1/den).
+__global__ void layernorm_cf_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                           const float* __restrict__ dy, float* __restrict__ dx,
+                                           float* __restrict__ stats, int n, int c, long long hw, float eps)
+{
+    const long long total = (long long)n * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / hw, pix = i - img * hw;
+        const float* xp = x + img * c * hw + pix;
+        const float* gp = dy + img * c * hw + pix;
+        float* dp = dx + img * c * hw + pix;
+        float u = 0.0f;
+        for (int k = 0; k < c; ++k) u += xp[(long long)k * hw];
+        u = u / (float)c;
+        float s = 0.0f;
+        for (int k = 0; k < c; ++k) { const float d = xp[(long long)k * hw] - u; s += d * d; }
+        s = s / (float)c;
+        const float rden = 1.0f / sqrtf(s + eps);
+        float mg = 0.0f, mgx = 0.0f;
+        for (int k = 0; k < c; ++k) {
+            const float xh = (xp[(long long)k * hw] - u) * rden, g = gp[(long long)k * hw] * weight[k];
+            mg += g; mgx += g * xh;
+        }
+        mg = mg / (float)c; mgx = mgx / (float)c;
+        for (int k = 0; k < c; ++k) {
+            const float xh = (xp[(long long)k * hw] - u) * rden, g = gp[(long long)k * hw] * weight[k];
+            dp[(long long)k * hw] = (g - mg - xh * mgx) * rden;
+        }
+        stats[2 * i] = u; stats[2 * i + 1] = rden;
+    }
+}
+
+// pass 2: block (k, slice) sums dy*xh and dy of channel k over its slice of the pixels in a fixed order
+// (strided per-thread sums, then a tree over the block); pass 3 adds the slices in order: deterministic.
+constexpr int kLnSlices = 64;
+__global__ __launch_bounds__(256) void layernorm_cf_bwd_param_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     const float* __restrict__ stats, float* __restrict__ partial,
+                                                                     int n, int c, long long hw)
+{
+    __shared__ float sw[256], sb[256];
+    const int k = blockIdx.x, slice = blockIdx.y;
+    const long long total = (long long)n * hw;
+    const long long per = (total + kLnSlices - 1) / kLnSlices;
+    const long long lo = slice * per, hi = lo + per < total ? lo + per : total;
+    float aw = 0.0f, ab = 0.0f;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const long long img = i / hw, pix = i - img * hw;
+        const long long o = (img * c + k) * hw + pix;
+        const float g = dy[o];
+        aw += g * ((x[o] - stats[2 * i]) * stats[2 * i + 1]);
+        ab += g;
+    }
+    sw[threadIdx.x] = aw; sb[threadIdx.x] = ab;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { sw[threadIdx.x] += sw[threadIdx.x + st]; sb[threadIdx.x] += sb[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[(k * kLnSlices + slice) * 2] = sw[0]; partial[(k * kLnSlices + slice) * 2 + 1] = sb[0]; }
+}
+
+__global__ void layernorm_cf_bwd_final_kernel(const float* __restrict__ partial, float* __restrict__ dweight,
+                                              float* __restrict__ dbias, int c)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c) return;
+    float aw = 0.0f, ab = 0.0f;
+    for (int sl = 0; sl < kLnSlices; ++sl) { aw += partial[(k * kLnSlices + sl) * 2]; ab += partial[(k * kLnSlices + sl) * 2 + 1]; }
+    dweight[k] = aw; dbias[k] = ab;
+}
+
 }  // namespace
 
 extern "C" {
+
+SRHIP_API size_t srhip_layernorm_cf_bwd_workspace_bytes(int n, int c, int hw)
+{
+    if (n < 1 || c < 1 || hw < 1) return 0;
+    return ((size_t)n * hw * 2 + (size_t)c * kLnSlices * 2) * sizeof(float);
+}
+
+SRHIP_API int srhip_layernorm_cf_bwd_f32(const float* x, const float* weight, const float* dy, float* dx, float* dweight,
+                                         float* dbias, void* workspace, int n, int c, int hw, float eps, void* stream)
+{
+    SRHIP_REQUIRE(x && weight && dy && dx && dweight && dbias && workspace, "layernorm_cf_bwd_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && hw >= 1, "layernorm_cf_bwd_f32: bad shape");
+    SRHIP_REQUIRE(c <= 65535, "layernorm_cf_bwd_f32: at most 65535 channels");
+    hipStream_t s = (hipStream_t)stream;
+    float* stats = (float*)workspace;
+    float* partial = stats + (size_t)n * hw * 2;
+    hipLaunchKernelGGL(layernorm_cf_bwd_dx_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0, s,
+                       x, weight, dy, dx, stats, n, c, (long long)hw, eps);
+    hipLaunchKernelGGL(layernorm_cf_bwd_param_kernel, dim3(c, kLnSlices), dim3(256), 0, s, x, dy, stats, partial, n, c, (long long)hw);
+    hipLaunchKernelGGL(layernorm_cf_bwd_final_kernel, dim3(srhip_div_up(c, 64)), dim3(64), 0, s, partial, dweight, dbias, c);
+    return srhip_check_launch("layernorm_cf_bwd_f32");
+}
 
 SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, int cpad,
                                           void* stream)

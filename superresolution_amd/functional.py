@@ -524,3 +524,37 @@ def layernorm_cf(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps:
     y = torch.empty_like(x)
     check(lib.srhip_layernorm_cf_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), n, c, h * w, eps, _stream()))
     return y
+
+
+def layernorm_cf_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, eps: float = 1e-6):
+    """-> (dx, dweight, dbias) of layernorm_cf."""
+    x = _req(x, torch.float32, "x")
+    weight = _req(weight, torch.float32, "weight")
+    dy = _req(dy, torch.float32, "dy")
+    if dy.shape != x.shape:
+        raise ValueError("layernorm_cf_bwd: dy must have the shape of x")
+    n, c, h, w = x.shape
+    dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
+    ws = torch.empty((lib.srhip_layernorm_cf_bwd_workspace_bytes(n, c, h * w),), dtype=torch.uint8, device=x.device)
+    check(lib.srhip_layernorm_cf_bwd_f32(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                         db.data_ptr(), ws.data_ptr(), n, c, h * w, eps, _stream()))
+    return dx, dw, db
+
+
+class _LayerNormCF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return layernorm_cf(x, weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw, db = layernorm_cf_bwd(x, weight, dy.contiguous(), ctx.eps)
+        return dx, dw, db, None
+
+
+def layernorm_cf_autograd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """Differentiable channels-first LayerNorm (core/arch/CAMixerSR.py:29-37 under loss.backward())."""
+    return _LayerNormCF.apply(x, weight, bias, eps)

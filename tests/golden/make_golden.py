@@ -196,6 +196,26 @@ def gen_ops():
     print("ops.npz", len(out), "arrays")
 
 
+def gen_layernorm_bwd():
+    """a-8 / a-13: autograd of the channels-first LayerNorm formula (CAMixerSR.py:32-37, evaluated with torch ops:
+    the class's module needs basicsr) -> tests/golden/ln_bwd.npz."""
+    g = torch.Generator().manual_seed(808)
+    out = {}
+    for tag, shape in (("a", (2, 60, 6, 9)), ("b", (1, 16, 5, 3)), ("c", (3, 7, 2, 11))):
+        x = rnd(g, *shape, lo=-2.0, hi=2.0).requires_grad_(True)
+        wt = (torch.rand(shape[1], generator=g) + 0.5).requires_grad_(True)
+        bs = (torch.randn(shape[1], generator=g) * 0.1).requires_grad_(True)
+        dy = rnd(g, *shape)
+        u = x.mean(1, keepdim=True)
+        s = (x - u).pow(2).mean(1, keepdim=True)
+        y = (x - u) / torch.sqrt(s + 1e-6)
+        y = wt[:, None, None] * y + bs[:, None, None]
+        y.backward(dy)
+        for k, v in (("x", x), ("w", wt), ("b", bs), ("dy", dy), ("y", y), ("dx", x.grad), ("dw", wt.grad), ("db", bs.grad)):
+            out[f"{tag}.{k}"] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "ln_bwd.npz"), **out)
+
+
 def gen_supersampler():
     from core.models.model import SuperSampler, LossGroup
     torch.manual_seed(42)
@@ -405,6 +425,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "reprfn_init":
         gen_reprfn_init()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "layernorm_bwd":
+        gen_layernorm_bwd()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_model":
         gen_temporal_model()
         sys.exit(0)
@@ -412,6 +435,7 @@ if __name__ == "__main__":
         gen_temporal_ops()
         sys.exit(0)
     gen_ops()
+    gen_layernorm_bwd()
     gen_supersampler()
     gen_reprfn()
     gen_reprfn_init()

@@ -316,3 +316,38 @@ def test_supersampler_forward_golden(ss_golden):
     # PSNR against the HR target moves by < 0.05 dB relative to the reference output
     hr = z["hr_frames"]
     assert abs(psnr(np.clip(sr, 0, 10), hr) - psnr(np.clip(ref, 0, 10), hr)) < 0.05
+
+
+def test_layernorm_cf_backward_golden_and_oracle(F_):
+    """Backward of the channels-first LayerNorm against torch autograd of the reference formula
+    (tests/golden/ln_bwd.npz) and the oracle; through the autograd wrapper as well.  fp32, tolerance 1e-5 relative
+    to the largest gradient."""
+    import os
+    from oracle import oracle as orc
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ln_bwd.npz"))
+    for tag in "abc":
+        x, w, b, dy = (torch.from_numpy(z[f"{tag}.{k}"]).cuda() for k in ("x", "w", "b", "dy"))
+        dx, dw, db = F_.layernorm_cf_bwd(x, w, dy)
+        odx, odw, odb = orc.layernorm_cf_bwd(z[f"{tag}.x"], z[f"{tag}.w"], z[f"{tag}.dy"])
+        for got, gold, o in ((dx, z[f"{tag}.dx"], odx), (dw, z[f"{tag}.dw"], odw), (db, z[f"{tag}.db"], odb)):
+            tol = 1e-5 * max(1.0, float(np.abs(gold).max()))
+            assert np.abs(got.cpu().numpy() - gold).max() <= tol
+            assert np.abs(got.cpu().numpy() - o).max() <= tol
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = F_.layernorm_cf_autograd(xr, wr, br)
+        assert np.abs(y.detach().cpu().numpy() - z[f"{tag}.y"]).max() <= 5e-6
+        y.backward(dy)
+        assert torch.equal(xr.grad, dx) and torch.equal(wr.grad, dw) and torch.equal(br.grad, db)
+
+
+def test_layernorm_cf_backward_large_is_deterministic(F_):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(2, 60, 270, 480, device="cuda", generator=g)
+    w = torch.rand(60, device="cuda", generator=g) + 0.5
+    dy = torch.randn(2, 60, 270, 480, device="cuda", generator=g)
+    a = F_.layernorm_cf_bwd(x, w, dy)
+    b = F_.layernorm_cf_bwd(x, w, dy)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    # dbias is a plain sum: check it against a float64 reduction
+    ref = dy.double().sum(dim=(0, 2, 3))
+    assert (a[2].double() - ref).abs().max().item() <= 1e-3

@@ -1,6 +1,8 @@
 """Pins the CPU oracle (oracle/) against goldens produced by the reference itself
 (tests/golden/make_golden.py).  Index / permutation ops must be bit-exact; convolution and
 bilinear sampling agree to 1e-5 (summation order differs from ATen's)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -197,3 +199,13 @@ def test_temporal_ops_oracle_golden(temporal_golden):
         y = orc.conv2d(z[key + ".x"], z[key + ".w"], z[key + ".b"], st, pd, act=1)
         assert np.abs(y - z[key + ".y"]).max() <= 5e-5, key
     assert np.abs(orc.resize_bilinear_align_corners(z["up2.x"], 10, 18) - z["up2.y"]).max() <= 2e-6
+
+
+def test_layernorm_cf_backward_oracle_vs_torch_autograd():
+    """tests/golden/ln_bwd.npz: torch autograd of the reference's channels-first LayerNorm formula."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ln_bwd.npz"))
+    for tag in "abc":
+        dx, dw, db = orc.layernorm_cf_bwd(z[f"{tag}.x"], z[f"{tag}.w"], z[f"{tag}.dy"])
+        _close(dx, z[f"{tag}.dx"], 1e-5)
+        _close(dw, z[f"{tag}.dw"], 1e-5 * max(1.0, float(np.abs(z[f"{tag}.dw"]).max())))
+        _close(db, z[f"{tag}.db"], 1e-5 * max(1.0, float(np.abs(z[f"{tag}.db"]).max())))
