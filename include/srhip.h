@@ -254,6 +254,20 @@ SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t 
 SRHIP_API int srhip_layernorm_cf_f32(const float* x, const float* weight, const float* bias, float* y,
                                      int n, int c, int hw, float eps, void* stream);
 
+/* Disocclusion logic of the temporal variant in one pass (core/models/model_final.py:472-486 and :501-504 over
+ * compute_mask_frame/_basecolor/_depth/_normal/_roughness/_metallic at :50-139; colour distance
+ * core/tools/color.py:22-31).  fp32 NCHW; G-buffer channels: normal 0:3, metallic 3, specular 4, roughness 5,
+ * base colour 6:9, depth 9.
+ *   cur_frame (B,3,h,w), cur_buffer (B,10,h,w), hist_frames (B,F,3,h,w), hist_buffer (B,F,10,h,w) (warped history)
+ *   mask (B,F,h,w) bytes or NULL; marked_frames (B*F,3,h,w); aux (B*F,14,h,w) = cur[0:3], cur[6:10],
+ *   marked hist[0:3], marked hist[6:10]; enhance_weight (B,h,w). */
+SRHIP_API int srhip_disocclusion_f32(const float* cur_frame, const float* cur_buffer, const float* hist_frames,
+                                     const float* hist_buffer, unsigned char* mask, float* marked_frames, float* aux,
+                                     float* enhance_weight, int b, int f, int h, int w, void* stream);
+
+/* Depth range compression (core/models/model_final.py:40-46); src may equal dst. */
+SRHIP_API int srhip_clamp_depth_f32(const float* src, float* dst, long long n, float thres1, float thres2, void* stream);
+
 /* Backward of the channels-first LayerNorm (autograd of core/arch/CAMixerSR.py:32-37 under loss.backward(),
  * core/trainer.py:160): dx (N,C,HW), dweight[C], dbias[C] (overwritten; fixed summation order).
  * workspace: srhip_layernorm_cf_bwd_workspace_bytes(n, c, hw) bytes of device memory. */

@@ -453,6 +453,88 @@ ORC_API void orc_layernorm_cf_bwd(const float* x, const float* weight, const flo
 }
 
 /* ------------------------------------------------------------------------- */
+/* Disocclusion logic of the temporal variant, composed as its forward does        */
+/* (core/models/model_final.py:472-486 and :501-504 over the functions at :50-139, */
+/* colour distance core/tools/color.py:22-31).  G-buffer channels: normal 0:3,     */
+/* metallic 3, specular 4, roughness 5, base colour 6:9, depth 9.                  */
+/*   mask  = frame(5x5 reflect min/max, all 3 channels outside) | colour(3x3       */
+/*           reflect, distance > 0.5 for more than 0.7 of the 9) | depth           */
+/*   marked_frames = mask ? 0 : hist_frames;  aux = cur[0:3], cur[6:10],           */
+/*           marked hist[0:3], marked hist[6:10];  enhance = mean of the normal,   */
+/*           roughness (< 0.02) and metallic (> 0.95) masks over history and kind  */
+/* ------------------------------------------------------------------------- */
+static int orc_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+ORC_API void orc_disocclusion(const float* cur_frame, const float* cur_buffer, const float* hist_frames,
+                              const float* hist_buffer, unsigned char* mask, float* marked_frames, float* aux,
+                              float* enhance, int B, int Fh, int H, int W)
+{
+    const size_t hw = (size_t)H * W;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const size_t pix = (size_t)y * W + x;
+                const float* cf = cur_frame + (size_t)b * 3 * hw;
+                const float* cb = cur_buffer + (size_t)b * 10 * hw;
+                float lo[3], hi[3];
+                for (int c = 0; c < 3; ++c) {
+                    lo[c] = INFINITY; hi[c] = -INFINITY;
+                    for (int dy = -2; dy <= 2; ++dy)
+                        for (int dx = -2; dx <= 2; ++dx) {
+                            const float v = cf[c * hw + (size_t)orc_reflect(y + dy, H) * W + orc_reflect(x + dx, W)];
+                            lo[c] = v < lo[c] ? v : lo[c]; hi[c] = v > hi[c] ? v : hi[c];
+                        }
+                }
+                int count = 0;
+                for (int f = 0; f < Fh; ++f) {
+                    const float* hf = hist_frames + ((size_t)b * Fh + f) * 3 * hw;
+                    const float* hb = hist_buffer + ((size_t)b * Fh + f) * 10 * hw;
+                    int m_frame = 1;
+                    for (int c = 0; c < 3; ++c) { const float v = hf[c * hw + pix]; m_frame &= (v < lo[c]) | (v > hi[c]); }
+                    int far = 0;
+                    const float r2 = hb[6 * hw + pix], b2 = hb[7 * hw + pix], g2 = hb[8 * hw + pix];
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const size_t q = (size_t)orc_reflect(y + dy, H) * W + orc_reflect(x + dx, W);
+                            const float r1 = cb[6 * hw + q], b1 = cb[7 * hw + q], g1 = cb[8 * hw + q];
+                            const float r = (r1 + r2) / 2.0f, dr = r1 - r2, dg = g1 - g2, db = b1 - b2;
+                            const float d = sqrtf(((2.0f + r) * (dr * dr) + 4.0f * (dg * dg)) + (2.0f + (1.0f - r)) * (db * db));
+                            far += d > 0.5f;
+                        }
+                    const int m_color = ((float)far / 9.0f) > 0.7f;
+                    const float cd = cb[9 * hw + pix], hd = hb[9 * hw + pix];
+                    const int m_depth = (cd - hd) > (0.1f * cd);
+                    const int m = m_frame | m_color | m_depth;
+                    const size_t bf = (size_t)b * Fh + f;
+                    if (mask) mask[bf * hw + pix] = (unsigned char)m;
+                    for (int c = 0; c < 3; ++c) marked_frames[(bf * 3 + c) * hw + pix] = m ? 0.0f : hf[c * hw + pix];
+                    float* a = aux + bf * 14 * hw + pix;
+                    for (int c = 0; c < 3; ++c) a[c * hw] = cb[c * hw + pix];
+                    for (int c = 0; c < 4; ++c) a[(3 + c) * hw] = cb[(6 + c) * hw + pix];
+                    for (int c = 0; c < 3; ++c) a[(7 + c) * hw] = m ? 0.0f : hb[c * hw + pix];
+                    for (int c = 0; c < 4; ++c) a[(10 + c) * hw] = m ? 0.0f : hb[(6 + c) * hw + pix];
+                    float dot = 0.0f;
+                    for (int c = 0; c < 3; ++c) dot += ((cb[c * hw + pix] - 0.5f) * 2.0f) * ((hb[c * hw + pix] - 0.5f) * 2.0f);
+                    count += !(fabsf(dot) < 1e-3f) && (dot < 0.707f);
+                    const float cr = cb[5 * hw + pix], cm = cb[3 * hw + pix];
+                    count += (cr < 0.02f) | (fabsf(cr - hb[5 * hw + pix]) > 0.25f);
+                    count += (cm > 0.95f) | (fabsf(cm - hb[3 * hw + pix]) > 0.25f);
+                }
+                enhance[(size_t)b * hw + pix] = (float)count / (float)(3 * Fh);
+            }
+}
+
+/* model_final.py:40-46 (the formula is the identity below thres1, so the host-side max() test is dropped) */
+ORC_API void orc_clamp_depth(const float* src, float* dst, long long n, float thres1, float thres2)
+{
+    for (long long i = 0; i < n; ++i) {
+        const float d = src[i];
+        dst[i] = d >= thres2 ? thres1 + log2f(thres2 - thres1) + log10f((d - thres2) + 1.0f)
+                             : (d >= thres1 ? thres1 + log2f((d - thres1) + 1.0f) : d);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Pieces used only by the RepRFN ESA block (core/arch/RepRFN.py:295-308):      */
 /* max_pool2d(k,s) without padding, bilinear resize align_corners=False.        */
 /* ------------------------------------------------------------------------- */

@@ -201,6 +201,26 @@ def layernorm_cf_bwd(x, weight, dy, eps=1e-6):
     return dx, dw, db
 
 
+def disocclusion(cur_frame, cur_buffer, hist_frames, hist_buffer):
+    """-> (mask (B,F,1,h,w) bool, marked_frames (B*F,3,h,w), aux (B*F,14,h,w), enhance_weight (B,1,h,w))."""
+    cur_frame, cur_buffer, hist_frames, hist_buffer = _c(cur_frame), _c(cur_buffer), _c(hist_frames), _c(hist_buffer)
+    B, Fh, _, H, W = hist_frames.shape
+    mask = np.empty((B, Fh, 1, H, W), np.uint8)
+    marked = np.empty((B * Fh, 3, H, W), np.float32)
+    aux = np.empty((B * Fh, 14, H, W), np.float32)
+    ew = np.empty((B, 1, H, W), np.float32)
+    lib().orc_disocclusion(_p(cur_frame), _p(cur_buffer), _p(hist_frames), _p(hist_buffer),
+                           mask.ctypes.data_as(ctypes.c_void_p), _p(marked), _p(aux), _p(ew), _i(B), _i(Fh), _i(H), _i(W))
+    return mask.astype(bool), marked, aux, ew
+
+
+def clamp_depth(depth, thres1=3.0, thres2=7.0):
+    depth = _c(depth)
+    out = np.empty_like(depth)
+    lib().orc_clamp_depth(_p(depth), _p(out), ctypes.c_longlong(depth.size), ctypes.c_float(thres1), ctypes.c_float(thres2))
+    return out
+
+
 def max_pool2d(x, k, s):
     x = _c(x)
     N, C, H, W = x.shape

@@ -614,6 +614,104 @@ __global__ void layernorm_cf_kernel(const float* __restrict__ x, const float* __
     }
 }
 
+// Disocclusion logic of the temporal variant in one pass over the LR frame (model_final.py:472-486,501-504 over
+// the mask functions at :50-139; colour distance core/tools/color.py:22-31).  One thread per (image, pixel):
+// the 5x5 range of the current frame and the 3x3 base-colour neighbourhood do not depend on the history index.
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+__global__ void disocclusion_kernel(const float* __restrict__ cur_frame, const float* __restrict__ cur_buffer,
+                                    const float* __restrict__ hist_frames, const float* __restrict__ hist_buffer,
+                                    unsigned char* __restrict__ mask, float* __restrict__ marked_frames,
+                                    float* __restrict__ aux, float* __restrict__ enhance, int fh, int h, int w)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const int y = blockIdx.y, b = blockIdx.z;
+    const int hw = h * w, pix = y * w + x;
+    const float* cf = cur_frame + (long long)b * 3 * hw;
+    const float* cb = cur_buffer + (long long)b * 10 * hw;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; }
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int row = reflect_idx(y + dy, h) * w;
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int q = row + reflect_idx(x + dx, w);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = cf[c * hw + q];
+                lo[c] = v < lo[c] ? v : lo[c];
+                hi[c] = v > hi[c] ? v : hi[c];
+            }
+        }
+    }
+    float nr[9], nb[9], ng[9];  // base colour of the 3x3 neighbourhood (channel 1 is named b, channel 2 g: color.py:23)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int q = reflect_idx(y + dy, h) * w + reflect_idx(x + dx, w);
+            const int k = (dy + 1) * 3 + dx + 1;
+            nr[k] = cb[6 * hw + q]; nb[k] = cb[7 * hw + q]; ng[k] = cb[8 * hw + q];
+        }
+    float cv[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) cv[c] = cb[c * hw + pix];
+    int count = 0;
+    for (int f = 0; f < fh; ++f) {
+        const long long bf = (long long)b * fh + f;
+        const float* hf = hist_frames + bf * 3 * hw + pix;
+        const float* hb = hist_buffer + bf * 10 * hw + pix;
+        float fv[3], hv[10];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fv[c] = hf[c * hw];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) hv[c] = hb[c * hw];
+        bool m_frame = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m_frame = m_frame && ((fv[c] < lo[c]) || (fv[c] > hi[c]));
+        int far = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float r = (nr[k] + hv[6]) / 2.0f, dr = nr[k] - hv[6], dg = ng[k] - hv[8], db = nb[k] - hv[7];
+            const float d = __fsqrt_rn(((2.0f + r) * (dr * dr) + 4.0f * (dg * dg)) + (2.0f + (1.0f - r)) * (db * db));
+            far += d > 0.5f ? 1 : 0;
+        }
+        const bool m_color = __fdiv_rn((float)far, 9.0f) > 0.7f;
+        const bool m_depth = (cv[9] - hv[9]) > (0.1f * cv[9]);
+        const bool m = m_frame || m_color || m_depth;
+        if (mask != nullptr) mask[bf * hw + pix] = m ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) marked_frames[(bf * 3 + c) * hw + pix] = m ? 0.0f : fv[c];
+        float* a = aux + bf * 14 * hw + pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c * hw] = cv[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[(3 + c) * hw] = cv[6 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[(7 + c) * hw] = m ? 0.0f : hv[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[(10 + c) * hw] = m ? 0.0f : hv[6 + c];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dot += ((cv[c] - 0.5f) * 2.0f) * ((hv[c] - 0.5f) * 2.0f);
+        count += (!(fabsf(dot) < 1e-3f) && (dot < 0.707f)) ? 1 : 0;
+        count += ((cv[5] < 0.02f) || (fabsf(cv[5] - hv[5]) > 0.25f)) ? 1 : 0;
+        count += ((cv[3] > 0.95f) || (fabsf(cv[3] - hv[3]) > 0.25f)) ? 1 : 0;
+    }
+    enhance[(long long)b * hw + pix] = __fdiv_rn((float)count, (float)(3 * fh));
+}
+
+__global__ void clamp_depth_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float t1, float t2,
+                                   float log2_span)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = src[i];
+        dst[i] = d >= t2 ? t1 + log2_span + log10f((d - t2) + 1.0f) : (d >= t1 ? t1 + log2f((d - t1) + 1.0f) : d);
+    }
+}
+
 // LayerNorm backward, pass 1: dx, and per pixel the two numbers pass 2 needs (mean, 1/den).
 __global__ void layernorm_cf_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                            const float* __restrict__ dy, float* __restrict__ dx,
@@ -689,6 +787,29 @@ __global__ void layernorm_cf_bwd_final_kernel(const float* __restrict__ partial,
 }  // namespace
 
 extern "C" {
+
+SRHIP_API int srhip_disocclusion_f32(const float* cur_frame, const float* cur_buffer, const float* hist_frames,
+                                     const float* hist_buffer, unsigned char* mask, float* marked_frames, float* aux,
+                                     float* enhance_weight, int b, int f, int h, int w, void* stream)
+{
+    SRHIP_REQUIRE(cur_frame && cur_buffer && hist_frames && hist_buffer && marked_frames && aux && enhance_weight,
+                  "disocclusion_f32: null pointer");
+    SRHIP_REQUIRE(b >= 1 && f >= 1 && h >= 3 && w >= 3, "disocclusion_f32: bad shape (reflect padding of 2 needs h, w >= 3)");
+    SRHIP_REQUIRE(h <= 65535 && b <= 65535 && (long long)b * f * 14 * h * w < (1ll << 40), "disocclusion_f32: shape too large");
+    SRHIP_REQUIRE((long long)h * w * 14 < (1ll << 31), "disocclusion_f32: a frame must stay below 2^31 elements");
+    hipLaunchKernelGGL(disocclusion_kernel, dim3(srhip_div_up(w, 64), h, b), dim3(64), 0, (hipStream_t)stream, cur_frame,
+                       cur_buffer, hist_frames, hist_buffer, mask, marked_frames, aux, enhance_weight, f, h, w);
+    return srhip_check_launch("disocclusion_f32");
+}
+
+SRHIP_API int srhip_clamp_depth_f32(const float* src, float* dst, long long n, float thres1, float thres2, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "clamp_depth_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && thres2 > thres1, "clamp_depth_f32: bad arguments");
+    hipLaunchKernelGGL(clamp_depth_kernel, dim3(grid_for(n, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream, src, dst,
+                       n, thres1, thres2, log2f(thres2 - thres1));
+    return srhip_check_launch("clamp_depth_f32");
+}
 
 SRHIP_API size_t srhip_layernorm_cf_bwd_workspace_bytes(int n, int c, int hw)
 {

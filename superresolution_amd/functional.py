@@ -558,3 +558,37 @@ class _LayerNormCF(torch.autograd.Function):
 def layernorm_cf_autograd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """Differentiable channels-first LayerNorm (core/arch/CAMixerSR.py:29-37 under loss.backward())."""
     return _LayerNormCF.apply(x, weight, bias, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# temporal variant: disocclusion logic, depth compression
+# ------------------------------------------------------------------------------------------------
+def disocclusion(cur_frame: torch.Tensor, cur_buffer: torch.Tensor, hist_frames: torch.Tensor, hist_buffer: torch.Tensor,
+                 want_mask: bool = False):
+    """core/models/model_final.py:472-486,501-504 in one kernel -> (marked_frames (B*F,3,h,w), aux (B*F,14,h,w),
+    enhance_weight (B,1,h,w)[, mask (B,F,1,h,w) bool])."""
+    cur_frame = _req(cur_frame, torch.float32, "cur_frame")
+    cur_buffer = _req(cur_buffer, torch.float32, "cur_buffer")
+    hist_frames = _req(hist_frames, torch.float32, "hist_frames")
+    hist_buffer = _req(hist_buffer, torch.float32, "hist_buffer")
+    b, f, cf, h, w = hist_frames.shape
+    if cf != 3 or tuple(cur_frame.shape) != (b, 3, h, w) or tuple(cur_buffer.shape) != (b, 10, h, w) \
+            or tuple(hist_buffer.shape) != (b, f, 10, h, w):
+        raise ValueError("disocclusion: expected cur_frame (B,3,h,w), cur_buffer (B,10,h,w), hist_frames (B,F,3,h,w), "
+                         "hist_buffer (B,F,10,h,w)")
+    dev = cur_frame.device
+    marked = torch.empty((b * f, 3, h, w), dtype=torch.float32, device=dev)
+    aux = torch.empty((b * f, 14, h, w), dtype=torch.float32, device=dev)
+    ew = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
+    mask = torch.empty((b, f, 1, h, w), dtype=torch.uint8, device=dev) if want_mask else None
+    check(lib.srhip_disocclusion_f32(cur_frame.data_ptr(), cur_buffer.data_ptr(), hist_frames.data_ptr(), hist_buffer.data_ptr(),
+                                     _ptr(mask), marked.data_ptr(), aux.data_ptr(), ew.data_ptr(), b, f, h, w, _stream()))
+    return (marked, aux, ew, mask.bool()) if want_mask else (marked, aux, ew)
+
+
+def clamp_depth(depth: torch.Tensor, thres1: float = 3.0, thres2: float = 7.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """core/models/model_final.py:40-46 (identity below thres1, so no host-side max() test)."""
+    depth = _req(depth, torch.float32, "depth")
+    out = torch.empty_like(depth) if out is None else out
+    check(lib.srhip_clamp_depth_f32(depth.data_ptr(), out.data_ptr(), depth.numel(), thres1, thres2, _stream()))
+    return out

@@ -213,7 +213,8 @@ class MainNetwork(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
-# disocclusion logic of the reference, composed from tensor operations (fp32 NCHW on the GPU)
+# disocclusion logic of the reference written with tensor operations: the readable statement of what the fused
+# kernel (functional.disocclusion) computes; the CPU suite pins these against the reference's outputs
 # ------------------------------------------------------------------------------------------------
 def clamp_depth(depth: Tensor, thres1: float = 3.0, thres2: float = 7.0) -> Tensor:
     """model_final.py:40-46 without the host-side max() test (the formula is the identity below thres1)."""
@@ -304,9 +305,9 @@ class SuperSampler(nn.Module):
     @torch.no_grad()
     def infer(self, lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer):
         # depth clamp, in place like the reference (model_final.py:462-463)
-        hr_buffer[:, -1] = clamp_depth(hr_buffer[:, -1])
-        lr_buffer[:, -1] = clamp_depth(lr_buffer[:, -1])
-        history_buffer[:, :, -1] = clamp_depth(history_buffer[:, :, -1])
+        hr_buffer[:, -1] = F_.clamp_depth(hr_buffer[:, -1])
+        lr_buffer[:, -1] = F_.clamp_depth(lr_buffer[:, -1])
+        history_buffer[:, :, -1] = F_.clamp_depth(history_buffer[:, :, -1])
         assert hr_buffer.max() < 10, "Depth value is too large"
 
         fmap_bf = self.buffers_encoder.run(hr_buffer.contiguous())
@@ -315,17 +316,12 @@ class SuperSampler(nn.Module):
         b, f, _, h, w = history_frames.shape
         warped_frames, warped_buffer, motion_vectors = backward_warping_history(motion_vectors, history_frames, history_buffer)
 
-        mask_frame = compute_mask_frame(lr_frame, warped_frames, ksize=5)
-        current_buffer = lr_buffer.view(b, 1, -1, h, w).expand_as(warped_buffer)
-        mask = mask_frame | compute_mask_basecolor(current_buffer[:, :, 6:9], warped_buffer[:, :, 6:9]) \
-            | compute_mask_depth(current_buffer[:, :, -1:], warped_buffer[:, :, -1:])
-        marked_frames = torch.where(mask, 0, warped_frames).view(b * f, -1, h, w)
-        marked_buffer = torch.where(mask, 0, warped_buffer)
-        aux_buffer = torch.cat((current_buffer[:, :, 0:3], current_buffer[:, :, 6:10], marked_buffer[:, :, 0:3],
-                                marked_buffer[:, :, 6:10]), dim=2).reshape(b * f, -1, h, w)
+        # masks, marked history, auxiliary planes and the loss weight in one kernel (model_final.py:472-486,501-504)
+        marked_frames, aux_buffer, enhance_weight = F_.disocclusion(lr_frame.float(), lr_buffer.float(), warped_frames.float(),
+                                                                    warped_buffer.float())
         aux_motion = motion_vectors.reshape(b * f, -1, h, w)
 
-        fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames.float().contiguous()))[0]
+        fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames))[0]
         fmap_history = self.history_refiner.run(fmap_history, aux_buffer, aux_motion)          # (b*f, h, w, hs)
         if f > 1:  # (b, f*hs, h, w) in the reference: history index major, then channels
             fmap_history = fmap_history.view(b, f, h, w, -1).permute(0, 2, 3, 1, 4).reshape(b, h, w, -1).contiguous()
@@ -337,8 +333,4 @@ class SuperSampler(nn.Module):
         wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)
         sr_frame = F_.conv3x3(F_.nchw_f32_to_nhwc_bf16(hr), wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)
 
-        mask_normal = compute_mask_normal(current_buffer[:, :, 0:3], warped_buffer[:, :, 0:3])
-        mask_rough = compute_mask_roughness(current_buffer[:, :, 5:6], warped_buffer[:, :, 5:6], mark_min_value=0.02)
-        mask_metal = compute_mask_metallic(current_buffer[:, :, 3:4], warped_buffer[:, :, 3:4], mark_max_value=0.95)
-        enhance_weight = torch.cat([mask_normal, mask_rough, mask_metal], dim=1).float().mean(dim=2, keepdim=True).mean(dim=1)
         return sr_frame, enhance_weight

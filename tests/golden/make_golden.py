@@ -361,6 +361,56 @@ def gen_temporal_ops():
     print("temporal_ops.npz:", len(out), "arrays")
 
 
+def gen_temporal_masks():
+    """Disocclusion logic of the temporal variant, run on the reference's own functions
+    (core/models/model_final.py:40-139) and composed as its forward does (:472-486, :501-504)
+    -> tests/golden/temporal_masks.npz."""
+    torch.cuda.current_device = lambda: "cpu"
+    from core.models import model_final as mf
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    for tag, (b, f, h, w) in {"a": (2, 2, 13, 17), "b": (1, 1, 6, 5), "c": (1, 3, 9, 22)}.items():
+        # spatially smooth content (a low-resolution random field, enlarged) plus fine noise: neighbouring pixels
+        # of a rendered frame are similar, and the masks compare against neighbourhoods
+        smooth = lambda c: F.interpolate(torch.rand(b, c, 3, 4, generator=g), size=(h, w), mode="bilinear", align_corners=True)
+        lr_frame = (smooth(3) + (torch.rand(b, 3, h, w, generator=g) - 0.5) * 0.05).clamp(0.0, 1.0)
+        lr_buffer = (smooth(10) + (torch.rand(b, 10, h, w, generator=g) - 0.5) * 0.05).clamp(0.0, 1.0)
+        lr_buffer[:, 9] *= 4.0
+        # history = current + small noise, with patches that deviate strongly (disoccluded regions)
+        noise = lambda *shape: (torch.rand(*shape, generator=g) - 0.5) * 0.08
+        big = lambda *shape: (torch.rand(*shape, generator=g) < 0.3).float() * (torch.rand(*shape, generator=g) - 0.5) * 1.6
+        warped_frames = (lr_frame[:, None] + noise(b, f, 3, h, w) + big(b, f, 1, h, w)).clamp(0.0, 1.0)
+        warped_buffer = lr_buffer[:, None] + noise(b, f, 10, h, w) + big(b, f, 10, h, w)
+        warped_buffer[:, :, :9] = warped_buffer[:, :, :9].clamp(0.0, 1.0)
+        warped_buffer[:, :, 9] = warped_buffer[:, :, 9].clamp(0.0, 4.0)
+        # a few exact ties and exact zeros of the normal dot product
+        warped_frames[:, :, :, 0, 0] = lr_frame[:, None, :, 0, 0]
+        lr_buffer[:, 0:3, 1, 1] = 0.5
+        current_buffer = lr_buffer.view(b, 1, -1, h, w).expand_as(warped_buffer)
+        m_frame = mf.compute_mask_frame(lr_frame, warped_frames, ksize=5)
+        m_color = mf.compute_mask_basecolor(current_buffer[:, :, 6:9], warped_buffer[:, :, 6:9])
+        m_depth = mf.compute_mask_depth(current_buffer[:, :, -1:], warped_buffer[:, :, -1:])
+        mask = m_frame | m_color | m_depth
+        marked_frames = torch.where(mask, 0, warped_frames).view(b * f, -1, h, w)
+        marked_buffer = torch.where(mask, 0, warped_buffer)
+        aux = torch.concat((current_buffer[:, :, 0:3], current_buffer[:, :, 6:10], marked_buffer[:, :, 0:3],
+                            marked_buffer[:, :, 6:10]), dim=2).reshape(b * f, -1, h, w)
+        m_n = mf.compute_mask_normal(current_buffer[:, :, 0:3], warped_buffer[:, :, 0:3])
+        m_r = mf.compute_mask_roughness(current_buffer[:, :, 5:6], warped_buffer[:, :, 5:6], mark_min_value=0.02)
+        m_m = mf.compute_mask_metallic(current_buffer[:, :, 3:4], warped_buffer[:, :, 3:4], mark_max_value=0.95)
+        ew = torch.concat([m_n, m_r, m_m], dim=1).float().mean(dim=2, keepdim=True).mean(dim=1)
+        depth = rnd(g, b, 1, h, w, lo=0.0, hi=12.0)
+        for k, v in (("lr_frame", lr_frame), ("lr_buffer", lr_buffer), ("warped_frames", warped_frames),
+                     ("warped_buffer", warped_buffer), ("mask_frame", m_frame), ("mask_color", m_color),
+                     ("mask_depth", m_depth), ("mask", mask), ("marked_frames", marked_frames), ("aux", aux),
+                     ("mask_normal", m_n), ("mask_rough", m_r), ("mask_metal", m_m), ("enhance_weight", ew),
+                     ("depth", depth), ("depth_clamped", mf.clamp_depth([depth.clone()])[0])):
+            out[f"{tag}.{k}"] = v.numpy()
+        print(tag, "mask fraction", float(mask.float().mean()), "frame", float(m_frame.float().mean()),
+              "color", float(m_color.float().mean()), "depth", float(m_depth.float().mean()), "ew mean", float(ew.mean()))
+    np.savez_compressed(os.path.join(OUT, "temporal_masks.npz"), **out)
+
+
 def gen_temporal_model():
     """Full forward of the temporal variant, core/models/model_final.py SuperSampler(3, 10, 4, 1), at LR 16x24.
     The reference's backward_warping (core/tools/math.py:10-17) permutes an already (x, y)-last grid and
@@ -428,6 +478,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "layernorm_bwd":
         gen_layernorm_bwd()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "temporal_masks":
+        gen_temporal_masks()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_model":
         gen_temporal_model()
         sys.exit(0)
@@ -440,4 +493,5 @@ if __name__ == "__main__":
     gen_reprfn()
     gen_reprfn_init()
     gen_temporal_ops()
+    gen_temporal_masks()
     gen_temporal_model()

@@ -79,3 +79,36 @@ def test_upsample_x2_align_corners_golden(F_, z):
     x2 = torch.from_numpy(rng.standard_normal((1, 32, 7, 11)).astype(np.float32)).to(torch.bfloat16).float().numpy()
     y2 = F_.resize_bilinear_nhwc(F_.nchw_f32_to_nhwc_bf16(dev(x2)), 14, 22, align_corners=True)
     assert np.abs(F_.nhwc_bf16_to_nchw_f32(y2, 32).cpu().numpy() - orc.resize_bilinear_align_corners(x2, 14, 22)).max() <= 2e-2
+
+
+def test_disocclusion_kernel_matches_reference_masks_exactly():
+    """Fused disocclusion kernel against the reference's own mask functions (tests/golden/temporal_masks.npz):
+    comparisons and selections only, so every output is bit-exact."""
+    from superresolution_amd import functional as F_
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "temporal_masks.npz"))
+    for t in "abc":
+        args = [torch.from_numpy(z[f"{t}.{k}"]).cuda() for k in ("lr_frame", "lr_buffer", "warped_frames", "warped_buffer")]
+        marked, aux, ew, mask = F_.disocclusion(*args, want_mask=True)
+        assert np.array_equal(mask.cpu().numpy(), z[t + ".mask"])
+        assert np.array_equal(marked.cpu().numpy(), z[t + ".marked_frames"])
+        assert np.array_equal(aux.cpu().numpy(), z[t + ".aux"])
+        assert np.array_equal(ew.cpu().numpy(), z[t + ".enhance_weight"])
+        d = F_.clamp_depth(torch.from_numpy(z[t + ".depth"]).cuda())
+        assert np.abs(d.cpu().numpy() - z[t + ".depth_clamped"]).max() <= 1e-6
+
+
+def test_disocclusion_kernel_vs_oracle_larger_shape():
+    from oracle import oracle as orc
+    from superresolution_amd import functional as F_
+    g = torch.Generator().manual_seed(12)
+    b, f, h, w = 2, 3, 67, 131
+    smooth = lambda c: torch.nn.functional.interpolate(torch.rand(b, c, 5, 7, generator=g), size=(h, w), mode="bilinear")
+    cf, cb = smooth(3), smooth(10)
+    cb[:, 9] *= 4.0
+    hf = (cf[:, None] + (torch.rand(b, f, 3, h, w, generator=g) - 0.5) * 0.3).clamp(0, 1)
+    hb = cb[:, None] + (torch.rand(b, f, 10, h, w, generator=g) - 0.5) * 0.6
+    om, omf, oaux, oew = orc.disocclusion(cf.numpy(), cb.numpy(), hf.numpy(), hb.numpy())
+    marked, aux, ew, mask = F_.disocclusion(cf.cuda(), cb.cuda(), hf.cuda(), hb.cuda(), want_mask=True)
+    assert 0.05 < om.mean() < 0.95
+    assert np.array_equal(mask.cpu().numpy(), om) and np.array_equal(marked.cpu().numpy(), omf)
+    assert np.array_equal(aux.cpu().numpy(), oaux) and np.array_equal(ew.cpu().numpy(), oew)
