@@ -265,6 +265,10 @@ SRHIP_API int srhip_disocclusion_f32(const float* cur_frame, const float* cur_bu
                                      const float* hist_buffer, unsigned char* mask, float* marked_frames, float* aux,
                                      float* enhance_weight, int b, int f, int h, int w, void* stream);
 
+/* Second half of nn.ConvTranspose2d(k=2, s=2) (core/models/model_final.py:198-203) written as a 1x1 convolution to
+ * 4*C channels: src (N,h,w,4C) bf16 with channel (i*2+j)*C + c  ->  dst (N,2h,2w,C), dst[2y+i][2x+j][c]. */
+SRHIP_API int srhip_depth_to_space2_nhwc(const void* src, void* dst, int n, int h, int w, int c, void* stream);
+
 /* Depth range compression (core/models/model_final.py:40-46); src may equal dst. */
 SRHIP_API int srhip_clamp_depth_f32(const float* src, float* dst, long long n, float thres1, float thres2, void* stream);
 

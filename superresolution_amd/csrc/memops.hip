@@ -703,6 +703,19 @@ __global__ void disocclusion_kernel(const float* __restrict__ cur_frame, const f
     enhance[(long long)b * hw + pix] = __fdiv_rn((float)count, (float)(3 * fh));
 }
 
+// (N,h,w,4C) with channel = (i*2+j)*C + c  ->  (N,2h,2w,C): out[2y+i][2x+j][c].  16-byte chunks.
+__global__ void depth_to_space2_nhwc_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int h, int w, int q)
+{
+    // grid: (chunks of an output row, output row, image); q = C/8 chunks per output pixel
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * w * q) return;
+    const int Y = blockIdx.y, n = blockIdx.z;
+    const int X = i / q, k = i - X * q;
+    const long long in_px = ((long long)n * h + (Y >> 1)) * w + (X >> 1);
+    const long long out_px = ((long long)n * 2 * h + Y) * (2 * w) + X;
+    dst[out_px * q + k] = src[in_px * 4 * q + ((Y & 1) * 2 + (X & 1)) * q + k];
+}
+
 __global__ void clamp_depth_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float t1, float t2,
                                    float log2_span)
 {
@@ -800,6 +813,17 @@ SRHIP_API int srhip_disocclusion_f32(const float* cur_frame, const float* cur_bu
     hipLaunchKernelGGL(disocclusion_kernel, dim3(srhip_div_up(w, 64), h, b), dim3(64), 0, (hipStream_t)stream, cur_frame,
                        cur_buffer, hist_frames, hist_buffer, mask, marked_frames, aux, enhance_weight, f, h, w);
     return srhip_check_launch("disocclusion_f32");
+}
+
+SRHIP_API int srhip_depth_to_space2_nhwc(const void* src, void* dst, int n, int h, int w, int c, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "depth_to_space2_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 8 && c % 8 == 0, "depth_to_space2_nhwc: bad shape (c %% 8 == 0)");
+    SRHIP_REQUIRE(2 * h <= 65535 && n <= 65535, "depth_to_space2_nhwc: at most 65535 output rows and images per call");
+    const int q = c / 8;
+    hipLaunchKernelGGL(depth_to_space2_nhwc_kernel, dim3(srhip_div_up((long long)2 * w * q, kThreads), 2 * h, n), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const uint4*)src, (uint4*)dst, h, w, q);
+    return srhip_check_launch("depth_to_space2_nhwc");
 }
 
 SRHIP_API int srhip_clamp_depth_f32(const float* src, float* dst, long long n, float thres1, float thres2, void* stream)

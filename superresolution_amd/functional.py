@@ -198,6 +198,24 @@ def conv_transpose2x2s2(src: torch.Tensor, weight: torch.Tensor, bias: Optional[
     return out
 
 
+def conv_transpose2x2s2_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
+    """nn.ConvTranspose2d(cin, cout, 2, 2) (+activation) on the MFMA kernel: with stride = kernel size every output
+    pixel (2y+i, 2x+j) depends on one input pixel only, out = W[:, :, i, j]^T x + b, i.e. a 1x1 convolution to
+    4*cout channels (phase-major) followed by a depth-to-space copy.  `weight` (cin, cout, 2, 2) may be a Parameter
+    (the rearranged weight and its packed form are cached).  Falls back to the direct kernel when cout % 8 != 0."""
+    cin, cout = weight.shape[0], weight.shape[1]
+    if cout % 8 != 0 or tuple(weight.shape[2:]) != (2, 2):
+        return conv_transpose2x2s2(x, weight.detach(), None if bias is None else bias.detach(), cin, act=act)
+    w1 = _cached_pack(weight, ("convT-as-1x1",),
+                      lambda: weight.detach().float().permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1).contiguous())
+    b1 = None if bias is None else _cached_pack(bias, ("convT-bias-x4",), lambda: bias.detach().float().repeat(4).contiguous())
+    y = conv2d_auto(x, w1, b1, stride=1, padding=0, act=act)
+    n, h, w, _ = x.shape
+    out = torch.empty((n, 2 * h, 2 * w, cout), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_depth_to_space2_nhwc(y.data_ptr(), out.data_ptr(), n, h, w, cout, _stream()))
+    return out
+
+
 def gradient_map(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """GradientMap (core/models/model_final.py:160-187) on an fp32 (N,C,H,W) tensor."""
     x = _req(x, torch.float32, "x")

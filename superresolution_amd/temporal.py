@@ -55,7 +55,7 @@ class TransConvActivation(nn.Sequential):
 
     def run(self, x: Tensor) -> Tensor:
         c = self[0]
-        return F_.conv_transpose2x2s2(x, c.weight.detach(), c.bias.detach(), c.in_channels, act=F_.ACT_RELU)
+        return F_.conv_transpose2x2s2_auto(x, c.weight, c.bias, act=F_.ACT_RELU)
 
 
 def _run_seq(seq: nn.Sequential, x: Tensor) -> Tensor:

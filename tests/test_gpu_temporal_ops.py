@@ -112,3 +112,27 @@ def test_disocclusion_kernel_vs_oracle_larger_shape():
     assert 0.05 < om.mean() < 0.95
     assert np.array_equal(mask.cpu().numpy(), om) and np.array_equal(marked.cpu().numpy(), omf)
     assert np.array_equal(aux.cpu().numpy(), oaux) and np.array_equal(ew.cpu().numpy(), oew)
+
+
+@pytest.mark.parametrize("name", ["t64_64", "t192_192"])
+def test_conv_transpose_on_mfma_golden(F_, z, name):
+    """The transposed convolution as a 1x1 MFMA layer to 4*cout channels plus a depth-to-space copy, against the
+    reference module's output and the oracle."""
+    x, w, b = z[f"convT.{name}.x"], z[f"convT.{name}.w"], z[f"convT.{name}.b"]
+    wp, bp = torch.nn.Parameter(dev(w)), torch.nn.Parameter(dev(b))
+    for _ in range(2):  # the second call uses the cached rearranged weight
+        y = F_.conv_transpose2x2s2_auto(F_.nchw_f32_to_nhwc_bf16(dev(x)), wp, bp, act=F_.ACT_RELU)
+        got = F_.nhwc_bf16_to_nchw_f32(y, w.shape[1]).cpu().numpy()
+        assert got.shape == z[f"convT.{name}.y"].shape
+        assert np.abs(got - z[f"convT.{name}.y"]).max() <= 2e-2
+        assert np.abs(got - orc.conv_transpose2x2s2(x, w, b, relu=True)).max() <= 2e-2
+
+
+def test_depth_to_space_is_a_permutation(F_):
+    from superresolution_amd._lib import check, lib
+    n, h, w, c = 2, 5, 7, 16
+    src = torch.arange(n * h * w * 4 * c, dtype=torch.float32).remainder(251.0).view(n, h, w, 4 * c).to(torch.bfloat16).cuda()
+    dst = torch.empty(n, 2 * h, 2 * w, c, dtype=torch.bfloat16, device="cuda")
+    check(lib.srhip_depth_to_space2_nhwc(src.data_ptr(), dst.data_ptr(), n, h, w, c, torch.cuda.current_stream().cuda_stream))
+    ref = src.view(n, h, w, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, c)
+    assert torch.equal(dst, ref)
