@@ -370,6 +370,9 @@ def run_aux_infer(args, world, rank, dev, dist):
 
 def main():
     args = parse()
+    if os.environ.get("SRHIP_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SRHIP_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -50,7 +50,14 @@ class FlatGradAllReducer:
         w = self.world_size
         if w == 1:
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal of the multi-rank path without RCCL (ranks sharing a GPU): gloo's own device path can stall
+            # behind a busy GPU, so the bucket crosses through host memory
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / w)
 
 
@@ -62,7 +69,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=No
     if not tensors:
         return
     flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    dist.broadcast(flat, src=src, group=process_group)
+    if flat.is_cuda and dist.get_backend(process_group) == "gloo":
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=process_group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=process_group)
     off = 0
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].view_as(t).to(t.dtype))
