@@ -269,6 +269,14 @@ SRHIP_API int srhip_disocclusion_f32(const float* cur_frame, const float* cur_bu
  * 4*C channels: src (N,h,w,4C) bf16 with channel (i*2+j)*C + c  ->  dst (N,2h,2w,C), dst[2y+i][2x+j][c]. */
 SRHIP_API int srhip_depth_to_space2_nhwc(const void* src, void* dst, int n, int h, int w, int c, void* stream);
 
+/* Sample decode of the data loader (core/data/supersampling_sequence.py:153-200, _load_and_augment with
+ * _fn_transform / _fn_transform_velocity): src fp16 (C,H,W) device array (the `arr_0` of a frame file) ->
+ * dst fp32 (C,crop_h,crop_w) = src[:, y1:y1+crop_h, x1:x1+crop_w], rows reversed if flip_rows (the reference's
+ * "hflip", np.flip(img, 1)), columns reversed if flip_cols ("vflip"); channel k negated when bit k of neg_mask
+ * is set (motion vectors: flip_rows -> bit 1, flip_cols -> bit 0). */
+SRHIP_API int srhip_crop_flip_f16_f32(const void* src, float* dst, int c, int h, int w, int x1, int y1, int crop_h, int crop_w,
+                                      int flip_rows, int flip_cols, unsigned neg_mask, void* stream);
+
 /* Depth range compression (core/models/model_final.py:40-46); src may equal dst. */
 SRHIP_API int srhip_clamp_depth_f32(const float* src, float* dst, long long n, float thres1, float thres2, void* stream);
 

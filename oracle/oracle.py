@@ -221,6 +221,28 @@ def clamp_depth(depth, thres1=3.0, thres2=7.0):
     return out
 
 
+def load_and_augment(arrays, crop=None, hflip=False, vflip=False, velocity=False):
+    """core/data/supersampling_sequence.py:153-200 on already-loaded `arr_0` arrays (fp16 CHW): crop (x1, y1, x2, y2),
+    the two flips (hflip reverses axis 1, vflip axis 2), the motion-vector sign fix, cast to fp32, stack."""
+    out = []
+    for a in arrays:
+        img = np.asarray(a)
+        if crop is not None:
+            x1, y1, x2, y2 = crop
+            img = img[:, y1:y2, x1:x2]
+        img = img.astype(np.float32)
+        if hflip:
+            img = img[:, ::-1, :].copy()
+            if velocity:
+                img[1] = -img[1]
+        if vflip:
+            img = img[:, :, ::-1].copy()
+            if velocity:
+                img[0] = -img[0]
+        out.append(np.ascontiguousarray(img))
+    return np.stack(out, axis=0)
+
+
 def max_pool2d(x, k, s):
     x = _c(x)
     N, C, H, W = x.shape

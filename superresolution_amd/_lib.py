@@ -84,6 +84,7 @@ _SIGNATURES = {
     "srhip_concat_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "srhip_layernorm_cf_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p]),
     "srhip_depth_to_space2_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "srhip_crop_flip_f16_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [ctypes.c_uint, c_void_p]),
     "srhip_disocclusion_f32": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p]),
     "srhip_clamp_depth_f32": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_float, c_float, c_void_p]),
     "srhip_layernorm_cf_bwd_workspace_bytes": (c_size_t, [c_int] * 3),

@@ -2,6 +2,8 @@
 // resampling (fixed-ratio up-sampling and motion-vector warp), pixel (un)shuffle, nearest
 // down-sampling, coordinate features, channel concat and channels-first LayerNorm.
 // One thread moves 16 bytes wherever the layout allows it; grids are capped and grid-strided.
+#include <hip/hip_fp16.h>
+
 #include "srhip_common.h"
 
 // The coordinate / index arithmetic below replays the reference's fp32 operator sequence one
@@ -716,6 +718,19 @@ __global__ void depth_to_space2_nhwc_kernel(const uint4* __restrict__ src, uint4
     dst[out_px * q + k] = src[in_px * 4 * q + ((Y & 1) * 2 + (X & 1)) * q + k];
 }
 
+// Sample decode of the data loader (core/data/supersampling_sequence.py:153-200): fp16 (C,H,W) -> fp32 crop with the
+// two flips; channel k is negated when bit k of neg_mask is set (the motion-vector sign fix of the flips).
+__global__ void crop_flip_f16_f32_kernel(const __half* __restrict__ src, float* __restrict__ dst, int h, int w, int x1, int y1,
+                                         int ch, int cw, int flip_rows, int flip_cols, unsigned neg_mask)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= cw) return;
+    const int y = blockIdx.y, c = blockIdx.z;
+    const int sy = y1 + (flip_rows ? ch - 1 - y : y), sx = x1 + (flip_cols ? cw - 1 - x : x);
+    const float v = __half2float(src[((long long)c * h + sy) * w + sx]);
+    dst[((long long)c * ch + y) * cw + x] = ((neg_mask >> c) & 1u) ? -v : v;
+}
+
 __global__ void clamp_depth_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float t1, float t2,
                                    float log2_span)
 {
@@ -824,6 +839,19 @@ SRHIP_API int srhip_depth_to_space2_nhwc(const void* src, void* dst, int n, int 
     hipLaunchKernelGGL(depth_to_space2_nhwc_kernel, dim3(srhip_div_up((long long)2 * w * q, kThreads), 2 * h, n), dim3(kThreads), 0,
                        (hipStream_t)stream, (const uint4*)src, (uint4*)dst, h, w, q);
     return srhip_check_launch("depth_to_space2_nhwc");
+}
+
+SRHIP_API int srhip_crop_flip_f16_f32(const void* src, float* dst, int c, int h, int w, int x1, int y1, int crop_h, int crop_w,
+                                      int flip_rows, int flip_cols, unsigned neg_mask, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "crop_flip_f16_f32: null pointer");
+    SRHIP_REQUIRE(c >= 1 && c <= 32 && h >= 1 && w >= 1, "crop_flip_f16_f32: bad shape (at most 32 channels)");
+    SRHIP_REQUIRE(x1 >= 0 && y1 >= 0 && crop_h >= 1 && crop_w >= 1 && x1 + crop_w <= w && y1 + crop_h <= h,
+                  "crop_flip_f16_f32: crop window (%d,%d)+(%dx%d) outside the %dx%d image", x1, y1, crop_w, crop_h, w, h);
+    SRHIP_REQUIRE(crop_h <= 65535, "crop_flip_f16_f32: at most 65535 rows");
+    hipLaunchKernelGGL(crop_flip_f16_f32_kernel, dim3(srhip_div_up(crop_w, kThreads), crop_h, c), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const __half*)src, dst, h, w, x1, y1, crop_h, crop_w, flip_rows, flip_cols, neg_mask);
+    return srhip_check_launch("crop_flip_f16_f32");
 }
 
 SRHIP_API int srhip_clamp_depth_f32(const float* src, float* dst, long long n, float thres1, float thres2, void* stream)

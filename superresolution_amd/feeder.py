@@ -1,0 +1,101 @@
+"""GPU-side sample feeder: the step in front of the network (core/data/supersampling_sequence.py:130-173).
+
+The reference loads every frame file (`np.load(path)["arr_0"]`, fp16 CHW), crops, flips and casts on the CPU, one
+array at a time, then stacks and uploads fp32.  Here the fp16 array goes to the GPU as it is (half the PCIe bytes,
+through pinned memory on a side stream) and one kernel per array does crop + flips + the motion-vector sign fix +
+the cast, writing straight into its slot of the clip tensor.  `prefetch()` stages the next sample while the
+current step computes.  Results are bit-identical to the reference loader (fp16 -> fp32 and negation are exact).
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+KEYS = ("anti-alias", "alias", "buffers", "velocity")
+
+
+def decode_crop_flip(src: torch.Tensor, crop: Optional[Tuple[int, int, int, int]] = None, hflip: bool = False,
+                     vflip: bool = False, velocity: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp16 (C,H,W) device tensor -> fp32 (C,h,w): `img[:, y1:y2, x1:x2]`, then the reference's flips
+    (`hflip` = np.flip(img, 1), i.e. rows; `vflip` = np.flip(img, 2), columns; supersampling_sequence.py:183-189),
+    for motion vectors with `motion[1] = -motion[1]` / `motion[0] = -motion[0]` (:192-198).  crop = (x1, y1, x2, y2)."""
+    if not src.is_cuda or src.dtype != torch.float16 or src.dim() != 3:
+        raise TypeError("decode_crop_flip: expected an fp16 (C,H,W) tensor on the GPU")
+    src = src.contiguous()
+    c, h, w = src.shape
+    x1, y1, x2, y2 = (0, 0, w, h) if crop is None else crop
+    ch, cw = y2 - y1, x2 - x1
+    if out is None:
+        out = torch.empty((c, ch, cw), dtype=torch.float32, device=src.device)
+    elif tuple(out.shape) != (c, ch, cw) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("decode_crop_flip: out must be a contiguous fp32 (C,h,w) tensor")
+    neg = ((2 if hflip else 0) | (1 if vflip else 0)) if velocity else 0
+    check(lib.srhip_crop_flip_f16_f32(src.data_ptr(), out.data_ptr(), c, h, w, x1, y1, ch, cw, int(hflip), int(vflip), neg,
+                                      torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+class SampleFeeder:
+    """Builds the reference's sample dict on the GPU.
+
+    `load(rows, crop, hflip, vflip)` takes the per-key lists of file paths (or already-loaded fp16 arrays) of one
+    sample — the `data_row` of supersampling_sequence.py:103-125 — and returns
+    {"anti-alias" (La,3,h,w), "alias" (L,3,h,w), "buffers" (L,10,h,w), "velocity" (L-1,2,h,w)} fp32 device tensors.
+    `prefetch(...)` starts the same work on a side stream; the next `load()` with no arguments returns it."""
+
+    def __init__(self, device: Optional[torch.device] = None) -> None:
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pending: Optional[Tuple[Dict[str, torch.Tensor], torch.cuda.Event, list]] = None
+
+    @staticmethod
+    def _array(item) -> np.ndarray:
+        a = np.load(item)["arr_0"] if isinstance(item, (str, bytes)) or hasattr(item, "__fspath__") else np.asarray(item)
+        if a.dtype != np.float16:
+            a = a.astype(np.float16)   # the files hold fp16 (tools/data_preprocess.py:30)
+        return np.ascontiguousarray(a)
+
+    def _build(self, rows: Dict[str, Sequence], crop, hflip: bool, vflip: bool):
+        out: Dict[str, torch.Tensor] = {}
+        keep = []  # pinned staging buffers stay alive until the copies have run
+        for key in KEYS:
+            items = [it for it in rows.get(key, []) if it is not None]
+            if not items:
+                continue
+            arrays = [self._array(it) for it in items]
+            c, h, w = arrays[0].shape
+            x1, y1, x2, y2 = (0, 0, w, h) if crop is None else crop
+            clip = torch.empty((len(arrays), c, y2 - y1, x2 - x1), dtype=torch.float32, device=self.device)
+            for i, a in enumerate(arrays):
+                pinned = torch.from_numpy(a).pin_memory()
+                dev = pinned.to(self.device, non_blocking=True)
+                keep.append((pinned, dev))
+                decode_crop_flip(dev, crop, hflip, vflip, velocity=(key == "velocity"), out=clip[i])
+            out[key] = clip
+        return out, keep
+
+    def prefetch(self, rows: Dict[str, Sequence], crop=None, hflip: bool = False, vflip: bool = False) -> None:
+        with torch.cuda.stream(self.stream):
+            out, keep = self._build(rows, crop, hflip, vflip)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self._pending = (out, done, keep)
+
+    def load(self, rows: Optional[Dict[str, Sequence]] = None, crop=None, hflip: bool = False, vflip: bool = False) -> Dict[str, torch.Tensor]:
+        if rows is not None:
+            self.prefetch(rows, crop, hflip, vflip)
+        if self._pending is None:
+            raise RuntimeError("SampleFeeder.load: nothing was prefetched")
+        out, done, _keep = self._pending
+        self._pending = None
+        torch.cuda.current_stream(self.device).wait_event(done)
+        for t in out.values():
+            t.record_stream(torch.cuda.current_stream(self.device))
+        return out
+
+
+def collate(samples: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
+    """Stack samples into the batch dict the trainer consumes (default collate of the reference's DataLoader)."""
+    return {k: torch.stack([s[k] for s in samples], dim=0) for k in samples[0]}

@@ -411,6 +411,41 @@ def gen_temporal_masks():
     np.savez_compressed(os.path.join(OUT, "temporal_masks.npz"), **out)
 
 
+def gen_feeder():
+    """Sample loading of the reference (core/data/supersampling_sequence.py:153-200): fp16 CHW `arr_0` arrays, crop,
+    flips (with the motion-vector sign fix), cast to fp32, stacked over the clip -> tests/golden/feeder.npz.
+    Runs the dataset class's own static methods on synthetic arrays written to a temporary directory."""
+    import tempfile
+    from core.data.supersampling_sequence import SuperSamplingDataset_Sequence as DS
+    from core.type_hints import CropRect, TransformParams
+    rng = np.random.default_rng(99)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        h, w = 22, 31
+        frames = [rng.random((3, h, w), dtype=np.float32).astype(np.float16) for _ in range(2)]
+        buffers = [rng.random((10, h, w), dtype=np.float32).astype(np.float16) for _ in range(2)]
+        motion = [((rng.random((2, h, w), dtype=np.float32) - 0.5) * 8).astype(np.float16) for _ in range(2)]
+        paths = {"frames": [], "buffers": [], "motion": []}
+        for kind, arrs in (("frames", frames), ("buffers", buffers), ("motion", motion)):
+            for i, a in enumerate(arrs):
+                pth = os.path.join(tmp, f"{kind}_{i}.npz")
+                np.savez_compressed(pth, a)
+                paths[kind].append(pth)
+                out[f"src.{kind}.{i}"] = a
+        cases = {"plain": (None, (False, False)), "crop": ((5, 3, 5 + 16, 3 + 12), (False, False)),
+                 "hflip": ((5, 3, 21, 15), (True, False)), "vflip": ((0, 0, 31, 22), (False, True)),
+                 "both": ((7, 2, 7 + 9, 2 + 17), (True, True))}
+        for name, (rect, (hf, vf)) in cases.items():
+            crop = None if rect is None else CropRect(*rect)
+            tr = None if rect is None else TransformParams(hf, vf, False)
+            out[f"{name}.rect"] = np.array([-1, -1, -1, -1] if rect is None else rect, np.int64)
+            out[f"{name}.flips"] = np.array([hf, vf], np.int64)
+            for kind, fn in (("frames", DS._fn_transform), ("buffers", DS._fn_transform), ("motion", DS._fn_transform_velocity)):
+                out[f"{name}.{kind}"] = DS._load_and_augment(paths[kind], crop, tr, fn).numpy()
+    np.savez_compressed(os.path.join(OUT, "feeder.npz"), **out)
+    print("feeder.npz:", len(out), "arrays")
+
+
 def gen_temporal_model():
     """Full forward of the temporal variant, core/models/model_final.py SuperSampler(3, 10, 4, 1), at LR 16x24.
     The reference's backward_warping (core/tools/math.py:10-17) permutes an already (x, y)-last grid and
@@ -478,6 +513,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "layernorm_bwd":
         gen_layernorm_bwd()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "feeder":
+        gen_feeder()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_masks":
         gen_temporal_masks()
         sys.exit(0)
@@ -494,4 +532,5 @@ if __name__ == "__main__":
     gen_reprfn_init()
     gen_temporal_ops()
     gen_temporal_masks()
+    gen_feeder()
     gen_temporal_model()

@@ -1,0 +1,76 @@
+"""Sample feeder (the step in front of the network) against the reference loader's own outputs
+(tests/golden/feeder.npz: core/data/supersampling_sequence.py `_load_and_augment` with `_fn_transform` /
+`_fn_transform_velocity`, run on synthetic fp16 frame files).  Everything is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "feeder.npz"))
+CASES = ["plain", "crop", "hflip", "vflip", "both"]
+
+
+def _case(name):
+    rect = tuple(int(v) for v in Z[name + ".rect"])
+    hf, vf = (bool(v) for v in Z[name + ".flips"])
+    return (None if rect[0] < 0 else rect), hf, vf
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_restatement_matches_reference_loader(name):
+    crop, hf, vf = _case(name)
+    for kind in ("frames", "buffers", "motion"):
+        src = [Z[f"src.{kind}.{i}"] for i in range(2)]
+        got = orc.load_and_augment(src, crop, hf, vf, velocity=(kind == "motion"))
+        assert got.dtype == np.float32 and np.array_equal(got, Z[f"{name}.{kind}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_decode_kernel_matches_reference_loader(name):
+    from superresolution_amd.feeder import decode_crop_flip
+    crop, hf, vf = _case(name)
+    for kind in ("frames", "buffers", "motion"):
+        for i in range(2):
+            src = torch.from_numpy(Z[f"src.{kind}.{i}"]).cuda()
+            got = decode_crop_flip(src, crop, hf, vf, velocity=(kind == "motion"))
+            assert np.array_equal(got.cpu().numpy(), Z[f"{name}.{kind}"][i])
+
+
+@pytest.mark.gpu
+def test_sample_feeder_from_files_with_prefetch(tmp_path):
+    from superresolution_amd.feeder import SampleFeeder, collate
+    paths = {"alias": [], "buffers": [], "velocity": [], "anti-alias": []}
+    for kind, key in (("frames", "alias"), ("buffers", "buffers"), ("motion", "velocity")):
+        for i in range(2):
+            p = tmp_path / f"{kind}_{i}.npz"
+            np.savez_compressed(p, Z[f"src.{kind}.{i}"])
+            paths[key].append(str(p))
+    paths["anti-alias"] = [paths["alias"][1]]
+    paths["velocity"] = [None, paths["velocity"][1]]      # the first frame of a clip has no motion vectors
+    fd = SampleFeeder()
+    crop, hf, vf = _case("both")
+    fd.prefetch(paths, crop, hf, vf)                      # staged on the side stream ...
+    busy = torch.rand(2048, 2048, device="cuda") @ torch.rand(2048, 2048, device="cuda")   # ... while this stream works
+    a = fd.load()
+    assert np.array_equal(a["alias"].cpu().numpy(), Z["both.frames"])
+    assert np.array_equal(a["buffers"].cpu().numpy(), Z["both.buffers"])
+    assert np.array_equal(a["velocity"].cpu().numpy(), Z["both.motion"][1:2])
+    assert np.array_equal(a["anti-alias"].cpu().numpy(), Z["both.frames"][1:2])
+    b = fd.load(paths, None)                              # synchronous form, whole frames
+    assert np.array_equal(b["buffers"].cpu().numpy(), Z["plain.buffers"])
+    batch = collate([a, a])
+    assert batch["alias"].shape == (2, 2, 3) + a["alias"].shape[-2:] and float(busy.sum()) > 0
+    with pytest.raises(RuntimeError):
+        fd.load()
+
+
+@pytest.mark.gpu
+def test_decode_rejects_windows_outside_the_image():
+    from superresolution_amd.feeder import decode_crop_flip
+    src = torch.zeros(3, 10, 12, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError):
+        decode_crop_flip(src, (5, 0, 14, 8))
