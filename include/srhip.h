@@ -265,6 +265,21 @@ SRHIP_API int srhip_disocclusion_f32(const float* cur_frame, const float* cur_bu
                                      const float* hist_buffer, unsigned char* mask, float* marked_frames, float* aux,
                                      float* enhance_weight, int b, int f, int h, int w, void* stream);
 
+/* Backward pieces of RepRFN under loss.backward() (core/trainer.py:160): LeakyReLU / ReLU from the activation's output
+ * (core/arch/RepRFN.py:17-33), and the ESA block's sigmoid gate, max_pool2d(7, 3) and bilinear resize (:295-308).
+ * NHWC bf16; dx / dgate are overwritten; all deterministic (gather forms, no atomics).
+ *   lrelu_mask:        dst = dy * (y > 0 ? 1 : slope)
+ *   sigmoid_gate_bwd:  y = x * sigmoid(gate)  ->  dx = dy * sig, dgate = dy * x * sig * (1 - sig)
+ *   max_pool2d_bwd:    src (N,h,w,c) the pooled input, dy (N,ho,wo,c) -> dx (N,h,w,c); first maximum wins a tie
+ *   resize_bilinear_bwd: dy (N,ho,wo,c) -> dx (N,h,w,c), adjoint of srhip_resize_bilinear_nhwc */
+SRHIP_API int srhip_lrelu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, float slope, void* stream);
+SRHIP_API int srhip_sigmoid_gate_bwd_bf16(const void* x, const void* gate, const void* dy, void* dx, void* dgate, size_t count,
+                                          void* stream);
+SRHIP_API int srhip_max_pool2d_bwd_nhwc(const void* src, const void* dy, void* dx, int n, int c, int h, int w, int k, int s,
+                                        void* stream);
+SRHIP_API int srhip_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int n, int c, int h, int w, int ho, int wo,
+                                             int align_corners, void* stream);
+
 /* Second half of nn.ConvTranspose2d(k=2, s=2) (core/models/model_final.py:198-203) written as a 1x1 convolution to
  * 4*C channels: src (N,h,w,4C) bf16 with channel (i*2+j)*C + c  ->  dst (N,2h,2w,C), dst[2y+i][2x+j][c]. */
 SRHIP_API int srhip_depth_to_space2_nhwc(const void* src, void* dst, int n, int h, int w, int c, void* stream);

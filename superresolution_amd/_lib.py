@@ -84,6 +84,10 @@ _SIGNATURES = {
     "srhip_concat_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "srhip_layernorm_cf_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p]),
     "srhip_depth_to_space2_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "srhip_lrelu_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
+    "srhip_sigmoid_gate_bwd_bf16": (c_int, [c_void_p] * 5 + [c_size_t, c_void_p]),
+    "srhip_max_pool2d_bwd_nhwc": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "srhip_resize_bilinear_bwd_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_void_p]),
     "srhip_crop_flip_f16_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [ctypes.c_uint, c_void_p]),
     "srhip_disocclusion_f32": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p]),
     "srhip_clamp_depth_f32": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_float, c_float, c_void_p]),

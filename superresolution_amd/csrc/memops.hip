@@ -337,6 +337,142 @@ __global__ void sigmoid_gate_kernel(const uint4* __restrict__ x, const uint4* __
     }
 }
 
+// ---- backward kernels of the ESA block and of LeakyReLU (autograd of core/arch/RepRFN.py:295-308,17-33) ----
+// dst = dy * (y > 0 ? 1 : slope): backward of (Leaky)ReLU from its OUTPUT (slope > 0 keeps the sign)
+__global__ void lrelu_mask_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y, uint4* __restrict__ dst,
+                                  long long nvec, float slope)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(dy[i], a);
+        unpack8(y[i], b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = b[e] > 0.0f ? a[e] : a[e] * slope;
+        dst[i] = pack8(a);
+    }
+}
+// y = x * sigmoid(g):  dx = dy * sig,  dg = dy * x * sig * (1 - sig)
+__global__ void sigmoid_gate_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ gate, const uint4* __restrict__ dy,
+                                        uint4* __restrict__ dx, uint4* __restrict__ dgate, long long nvec)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float a[8], b[8], d[8], o1[8], o2[8];
+        unpack8(x[i], a);
+        unpack8(gate[i], b);
+        unpack8(dy[i], d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.0f / (1.0f + expf(-b[e]));
+            o1[e] = d[e] * sg;
+            o2[e] = d[e] * a[e] * sg * (1.0f - sg);
+        }
+        dx[i] = pack8(o1);
+        dgate[i] = pack8(o2);
+    }
+}
+// max_pool2d(k, s) backward, gather form: an input pixel receives dy of every window in which it is the FIRST
+// maximum in row-major order (the forward kernel's and ATen's tie rule).  Deterministic, no atomics.
+__global__ void max_pool_bwd_nhwc_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ dy,
+                                         unsigned short* __restrict__ dx, int n, int c, int h, int w, int ho, int wo, int k, int s)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * h * w * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int x = (int)(p % w); p /= w;
+        const int y = (int)(p % h);
+        const int img = (int)(p / h);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+        const int oy_lo = y - k + 1 > 0 ? (y - k + 1 + s - 1) / s : 0, oy_hi = y / s < ho - 1 ? y / s : ho - 1;
+        const int ox_lo = x - k + 1 > 0 ? (x - k + 1 + s - 1) / s : 0, ox_hi = x / s < wo - 1 ? x / s : wo - 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                float m[8];
+                int arg[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; arg[e] = -1; }
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx) {
+                        float v[8];
+                        unpack8(*(const uint4*)(src + (((long long)img * h + oy * s + ky) * w + ox * s + kx) * c + g * 8), v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; arg[e] = ky * k + kx; }
+                    }
+                const int mine = (y - oy * s) * k + (x - ox * s);
+                float d[8];
+                unpack8(*(const uint4*)(dy + (((long long)img * ho + oy) * wo + ox) * c + g * 8), d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (arg[e] == mine) acc[e] += d[e];
+            }
+        *(uint4*)(dx + (((long long)img * h + y) * w + x) * c + g * 8) = pack8(acc);
+    }
+}
+// bilinear resize backward, gather form: source pixel (y, x) sums w_y * w_x * dy over the output pixels whose
+// four taps include it.  The tap positions and weights replay the forward kernel's arithmetic.
+__device__ __forceinline__ void resize_taps(int o, int n_in, float scale, int align, int& i0, int& i1, float& l)
+{
+    float f = align ? __fmul_rn(scale, (float)o) : __fsub_rn(__fmul_rn(scale, (float)o + 0.5f), 0.5f);
+    if (f < 0.0f) f = 0.0f;
+    i0 = (int)f;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l = f - (float)i0;
+}
+__global__ void resize_bilinear_bwd_nhwc_kernel(const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx, int n, int c,
+                                                int h, int w, int ho, int wo, int align)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * h * w * cg;
+    const float sy = align ? (ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.0f) : (float)h / (float)ho;
+    const float sx = align ? (wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.0f) : (float)w / (float)wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int x = (int)(p % w); p /= w;
+        const int y = (int)(p % h);
+        const int img = (int)(p / h);
+        // conservative range of output rows / columns whose taps can touch (y, x)
+        int oy_lo = sy > 0.0f ? (int)floorf(((float)y - 1.0f + 0.5f) / sy - 0.5f) - 1 : 0;
+        int oy_hi = sy > 0.0f ? (int)ceilf(((float)y + 1.0f + 0.5f) / sy - 0.5f) + 1 : ho - 1;
+        int ox_lo = sx > 0.0f ? (int)floorf(((float)x - 1.0f + 0.5f) / sx - 0.5f) - 1 : 0;
+        int ox_hi = sx > 0.0f ? (int)ceilf(((float)x + 1.0f + 0.5f) / sx - 0.5f) + 1 : wo - 1;
+        if (y == 0) oy_lo = 0;
+        if (x == 0) ox_lo = 0;
+        oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+        oy_hi = oy_hi > ho - 1 ? ho - 1 : oy_hi; ox_hi = ox_hi > wo - 1 ? wo - 1 : ox_hi;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly;
+            resize_taps(oy, h, sy, align, y0, y1, ly);
+            float wy = 0.0f;
+            if (y0 == y) wy += 1.0f - ly;
+            if (y1 == y) wy += ly;
+            if (y0 == y1 && y0 == y) wy = 1.0f;  // clamped at the last row: both taps are this row, weights sum to 1
+            if (wy == 0.0f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx;
+                resize_taps(ox, w, sx, align, x0, x1, lx);
+                float wx = 0.0f;
+                if (x0 == x) wx += 1.0f - lx;
+                if (x1 == x) wx += lx;
+                if (x0 == x1 && x0 == x) wx = 1.0f;
+                if (wx == 0.0f) continue;
+                float d[8];
+                unpack8(*(const uint4*)(dy + (((long long)img * ho + oy) * wo + ox) * c + g * 8), d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += wy * wx * d[e];
+            }
+        }
+        *(uint4*)(dx + (((long long)img * h + y) * w + x) * c + g * 8) = pack8(acc);
+    }
+}
+
 // GradientMap (core/models/model_final.py:160-187) on fp32 planes: sqrt(gv^2 + gh^2 + eps) with the fixed
 // stencils kernel_v = rows (-1, 0, +1), kernel_h = columns (-1, 0, +1), zero padding.
 __global__ void gradient_map_kernel(const float* __restrict__ src, float* __restrict__ dst, long long planes, int h, int w,
@@ -1140,6 +1276,53 @@ SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst
     hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4*)x, (const uint4*)gate, (uint4*)dst, nvec);
     return srhip_check_launch("sigmoid_gate_bf16");
+}
+
+SRHIP_API int srhip_lrelu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, float slope, void* stream)
+{
+    SRHIP_REQUIRE(dy && y && dst, "lrelu_mask_bf16: null pointer");
+    SRHIP_REQUIRE(count % 8 == 0, "lrelu_mask_bf16: count must be a multiple of 8");
+    SRHIP_REQUIRE(slope >= 0.0f, "lrelu_mask_bf16: the mask is read from the activation's output, which needs slope >= 0");
+    if (count == 0) return SRHIP_OK;
+    const long long nvec = (long long)(count / 8);
+    hipLaunchKernelGGL(lrelu_mask_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)dy, (const uint4*)y, (uint4*)dst, nvec, slope);
+    return srhip_check_launch("lrelu_mask_bf16");
+}
+
+SRHIP_API int srhip_sigmoid_gate_bwd_bf16(const void* x, const void* gate, const void* dy, void* dx, void* dgate, size_t count,
+                                          void* stream)
+{
+    SRHIP_REQUIRE(x && gate && dy && dx && dgate, "sigmoid_gate_bwd_bf16: null pointer");
+    SRHIP_REQUIRE(count % 8 == 0, "sigmoid_gate_bwd_bf16: count must be a multiple of 8");
+    if (count == 0) return SRHIP_OK;
+    const long long nvec = (long long)(count / 8);
+    hipLaunchKernelGGL(sigmoid_gate_bwd_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)x, (const uint4*)gate, (const uint4*)dy, (uint4*)dx, (uint4*)dgate, nvec);
+    return srhip_check_launch("sigmoid_gate_bwd_bf16");
+}
+
+SRHIP_API int srhip_max_pool2d_bwd_nhwc(const void* src, const void* dy, void* dx, int n, int c, int h, int w, int k, int s,
+                                        void* stream)
+{
+    SRHIP_REQUIRE(src && dy && dx, "max_pool2d_bwd_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && k >= 1 && s >= 1 && h >= k && w >= k, "max_pool2d_bwd_nhwc: bad shape");
+    const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
+    const long long work = (long long)n * h * w * (c / 8);
+    hipLaunchKernelGGL(max_pool_bwd_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, (const unsigned short*)dy, (unsigned short*)dx, n, c, h, w, ho, wo, k, s);
+    return srhip_check_launch("max_pool2d_bwd_nhwc");
+}
+
+SRHIP_API int srhip_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int n, int c, int h, int w, int ho, int wo,
+                                             int align_corners, void* stream)
+{
+    SRHIP_REQUIRE(dy && dx, "resize_bilinear_bwd_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && h >= 1 && w >= 1 && ho >= 1 && wo >= 1, "resize_bilinear_bwd_nhwc: bad shape");
+    const long long work = (long long)n * h * w * (c / 8);
+    hipLaunchKernelGGL(resize_bilinear_bwd_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)dy, (unsigned short*)dx, n, c, h, w, ho, wo, align_corners ? 1 : 0);
+    return srhip_check_launch("resize_bilinear_bwd_nhwc");
 }
 
 SRHIP_API int srhip_gradient_map_f32(const float* src, float* dst, int planes, int h, int w, float eps, void* stream)

@@ -610,3 +610,45 @@ def clamp_depth(depth: torch.Tensor, thres1: float = 3.0, thres2: float = 7.0, o
     out = torch.empty_like(depth) if out is None else out
     check(lib.srhip_clamp_depth_f32(depth.data_ptr(), out.data_ptr(), depth.numel(), thres1, thres2, _stream()))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# backward pieces of RepRFN (LeakyReLU from its output, ESA gate / pool / resize)
+# ------------------------------------------------------------------------------------------------
+def lrelu_mask(dy: torch.Tensor, y: torch.Tensor, slope: float) -> torch.Tensor:
+    """dy * (y > 0 ? 1 : slope) (bf16): backward of LeakyReLU(slope) / ReLU (slope 0) from the activation's output."""
+    dy = _req(dy, torch.bfloat16, "dy")
+    y = _req(y, torch.bfloat16, "y")
+    if dy.shape != y.shape:
+        raise ValueError("lrelu_mask: shapes differ")
+    out = torch.empty_like(dy)
+    check(lib.srhip_lrelu_mask_bf16(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), slope, _stream()))
+    return out
+
+
+def sigmoid_gate_bwd(x: torch.Tensor, gate: torch.Tensor, dy: torch.Tensor):
+    x, gate, dy = _req(x, torch.bfloat16, "x"), _req(gate, torch.bfloat16, "gate"), _req(dy, torch.bfloat16, "dy")
+    if x.shape != gate.shape or x.shape != dy.shape:
+        raise ValueError("sigmoid_gate_bwd: shapes differ")
+    dx, dg = torch.empty_like(x), torch.empty_like(x)
+    check(lib.srhip_sigmoid_gate_bwd_bf16(x.data_ptr(), gate.data_ptr(), dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), x.numel(), _stream()))
+    return dx, dg
+
+
+def max_pool2d_bwd_nhwc(x: torch.Tensor, dy: torch.Tensor, k: int, s: int) -> torch.Tensor:
+    x, dy = _req(x, torch.bfloat16, "x"), _req(dy, torch.bfloat16, "dy")
+    n, h, w, c = x.shape
+    if tuple(dy.shape) != (n, (h - k) // s + 1, (w - k) // s + 1, c):
+        raise ValueError("max_pool2d_bwd_nhwc: dy does not have the pooled shape")
+    dx = torch.empty_like(x)
+    check(lib.srhip_max_pool2d_bwd_nhwc(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c, h, w, k, s, _stream()))
+    return dx
+
+
+def resize_bilinear_bwd_nhwc(dy: torch.Tensor, h: int, w: int, align_corners: bool = False) -> torch.Tensor:
+    """Adjoint of resize_bilinear_nhwc: dy (N,ho,wo,C) -> gradient of the (N,h,w,C) source."""
+    dy = _req(dy, torch.bfloat16, "dy")
+    n, ho, wo, c = dy.shape
+    dx = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=dy.device)
+    check(lib.srhip_resize_bilinear_bwd_nhwc(dy.data_ptr(), dx.data_ptr(), n, c, h, w, ho, wo, int(align_corners), _stream()))
+    return dx

@@ -12,8 +12,9 @@ form the equivalent 3x3 kernel is re-parameterised from the nine branches each t
 change (a 48x48x3x3 tensor: weight algebra, not activation work), which gives the deploy result for
 a training-form state dict without materialising nine branch outputs.  The ESA block
 (RepRFN.py:281-308) runs on the small-convolution, pooling, resize and gating kernels.
-Inference only: calling the module with autograd enabled raises (the HIP training path covers the
-default network).
+With autograd enabled the module runs `forward_train`: the same graph from differentiable operators
+(`autograd_ops.py`), each RepBlock still ONE convolution whose merged kernel is differentiated back to the nine
+branches.
 """
 from typing import Tuple
 
@@ -100,6 +101,27 @@ class RepBlock(nn.Module):
             b += sb
         return k, b
 
+    def equivalent_kernel_bias_autograd(self) -> Tuple[Tensor, Tensor]:
+        """get_equivalent_kernel_bias written with out-of-place operations, so that the gradient of the merged
+        kernel flows back to the nine branches (the train-time branch fusion: one convolution per block instead
+        of nine, RepRFN.py:183-191)."""
+        if self.deploy:
+            return self.rbr_reparam.weight, self.rbr_reparam.bias
+        pad = torch.nn.functional.pad
+        k = (self.rbr_3x3_branch.weight + pad(self.rbr_1x1_branch.weight, (1, 1, 1, 1))
+             + pad(self.rbr_1x3_branch.weight, (0, 0, 1, 1)) + pad(self.rbr_3x1_branch.weight, (1, 1, 0, 0))
+             + torch.einsum("omyx,mi->oiyx", self.rbr_1x1_3x3_branch_3x3.weight, self.rbr_1x1_3x3_branch_1x1.weight[:, :, 0, 0]))
+        b = self.rbr_3x3_branch.bias + self.rbr_1x1_branch.bias + self.rbr_1x3_branch.bias + self.rbr_3x1_branch.bias
+        ident = torch.zeros_like(k)
+        idx = torch.arange(min(self.in_channels, self.out_channels), device=k.device)
+        ident[idx, idx, 1, 1] = 1.0
+        k = k + ident
+        for seq in (self.rbr_conv1x1_sbx_branch, self.rbr_conv1x1_sby_branch, self.rbr_conv1x1_lpl_branch):
+            sk, sb = seq.rep_params()
+            k = k + sk
+            b = b + sb
+        return k, b
+
     def switch_to_deploy(self) -> None:
         if self.deploy:
             return
@@ -151,6 +173,23 @@ class ESA(nn.Module):
         return F_.sigmoid_gate(x, c4)
 
 
+def _esa_train(esa: "ESA", x: Tensor) -> Tensor:
+    """ESA.run with differentiable operators (x: 64-channel padded feature map)."""
+    from . import autograd_ops as A
+    cs = x.shape[-1]
+    c1_ = A.conv1x1(x, esa.conv1.weight, esa.conv1.bias)
+    # 3x3 / stride 2 / pad 0 = the stride-1 pad-1 layer at the odd pixels (2o + 1)
+    full = A.conv3x3(c1_, esa.conv2.weight, esa.conv2.bias)
+    ho, wo = (full.shape[1] - 3) // 2 + 1, (full.shape[2] - 3) // 2 + 1
+    c1 = full[:, 1:2 * ho:2, 1:2 * wo:2, :].contiguous()
+    v_max = A.max_pool2d(c1, 7, 3)
+    c3 = A.conv3x3(v_max, esa.conv3.weight, esa.conv3.bias)
+    cf = A.conv1x1(c1_, esa.conv_f.weight, esa.conv_f.bias)
+    s = A.resize_add(c3, cf)
+    c4 = A.conv1x1(s, esa.conv4.weight, esa.conv4.bias, cout_stride=cs)
+    return A.sigmoid_gate(x, c4)
+
+
 class RepRFB(nn.Module):
     def __init__(self, feature_nums: int, act_type: str = "lrelu", deploy: bool = False) -> None:
         super().__init__()
@@ -197,9 +236,31 @@ class RepRFN(nn.Module):
 
     def forward(self, inputs: Tensor) -> Tensor:
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("RepRFN on libsrhip is inference-only: call it under torch.no_grad() "
-                                      "(the HIP training path covers superresolution_amd.SuperSampler)")
+            return self.forward_train(inputs)
         return self.infer(inputs)
+
+    def forward_train(self, inputs: Tensor) -> Tensor:
+        """Differentiable forward (core/trainer.py:158-161 works unchanged): the same graph as infer(), each RepBlock
+        as ONE convolution with the kernel merged from its nine branches by differentiable weight algebra, every
+        activation-space operator and its backward on the HIP kernels.  Feature maps travel padded to 64 channels."""
+        from . import autograd_ops as A
+        fn = self.feature_nums
+        cs = 64 if fn > 32 else F_.pad16(fn)          # channel counts the weight-gradient kernel tiles: 16, 32, 64
+        x = F_.nchw_f32_to_nhwc_bf16(inputs.detach().float())
+        fea = A.conv3x3(x, self.fea_conv.weight, self.fea_conv.bias, cout_stride=cs)
+        out = fea
+        for bi in range(1, 5):
+            rfb = getattr(self, f"reprfb{bi}")
+            t = out
+            for ri in range(1, 4):
+                k, b = getattr(rfb, f"repblock{ri}").equivalent_kernel_bias_autograd()
+                t = A.conv3x3(t, k, b, act=F_.ACT_LRELU, slope=_SLOPE, cout_stride=cs)
+            t = A.add(A.conv3x3(t, rfb.conv3.weight, rfb.conv3.bias, act=F_.ACT_LRELU, slope=_SLOPE, cout_stride=cs), out)
+            out = _esa_train(rfb.esa, t)
+        out = A.add(A.conv3x3(out, self.lr_conv.weight, self.lr_conv.bias, cout_stride=cs), fea)
+        up = self.upsampler
+        c = A.conv3x3(out, up.conv.weight, up.conv.bias, cout_stride=64 if up.conv.out_channels > 32 else None)
+        return A.pixel_shuffle_out(c, self.out_channels, up.upscale_factor)
 
     @torch.no_grad()
     def infer(self, inputs: Tensor) -> Tensor:

@@ -307,6 +307,40 @@ def gen_reprfn():
     print("reprfn.npz: y mean", y.abs().mean().item(), "params", sum(p.numel() for p in m.parameters()))
 
 
+def gen_reprfn_train():
+    """RepRFN in its TRAINING form (nine branches per block, RepRFN.py:183-191) run by the reference itself:
+    forward and the gradient of sum(y * r) w.r.t. every parameter -> tests/golden/reprfn_train.npz.  The weights are
+    not stored: seed 21 + bf16 rounding reproduces them (the construction order is identical); gradients are stored
+    as fp16 of grad / max|grad| plus the scale."""
+    from core.arch.RepRFN import RepRFN
+    torch.manual_seed(21)
+    m = RepRFN(3, 3, 48, 4, deploy=False)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.requires_grad:
+                p_.copy_(bf16_round(p_))
+    m.train()
+    g = torch.Generator().manual_seed(22)
+    x = bf16_round(rnd(g, 2, 3, 20, 28, lo=0.0, hi=1.0))
+    r = rnd(g, 2, 3, 80, 112)
+    y = m(x)
+    (y * r).sum().backward()
+    out = {"x": x.numpy(), "r": r.numpy(), "y": y.detach().numpy()}
+    names = []
+    for name, p_ in m.named_parameters():
+        if not p_.requires_grad:
+            continue
+        names.append(name)
+        gr = p_.grad.detach()
+        sc = float(gr.abs().max())
+        out["gscale." + name] = np.float32(sc)
+        out["g." + name] = (gr / max(sc, 1e-30)).numpy().astype(np.float16)
+        out["digest." + name] = np.array([p_.detach().double().sum().item(), p_.detach().double().abs().sum().item()])
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "reprfn_train.npz"), **out)
+    print("reprfn_train.npz:", len(names), "parameter gradients, y mean", float(y.abs().mean()))
+
+
 def gen_reprfn_init():
     """Digest of the seed-42 initialisation of RepRFN in its training form (first 8 values + fp64 sum
     of every state-dict entry) and the key lists of both forms."""
@@ -513,6 +547,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "layernorm_bwd":
         gen_layernorm_bwd()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "reprfn_train":
+        gen_reprfn_train()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "feeder":
         gen_feeder()
         sys.exit(0)
@@ -529,6 +566,7 @@ if __name__ == "__main__":
     gen_layernorm_bwd()
     gen_supersampler()
     gen_reprfn()
+    gen_reprfn_train()
     gen_reprfn_init()
     gen_temporal_ops()
     gen_temporal_masks()

@@ -67,8 +67,31 @@ def test_switch_to_deploy_yields_deploy_state_dict(init_golden):
     d.load_state_dict(m.state_dict(), strict=True)
 
 
-def test_forward_with_grad_raises():
+def test_forward_without_a_gpu_fails_loudly():
+    """Both the inference and the training graph run on the HIP library only: a CPU tensor is refused."""
     from superresolution_amd.reprfn import RepRFN
     m = RepRFN(deploy=True)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="no CPU path"):
         m(torch.zeros(1, 3, 8, 8))
+    with torch.no_grad(), pytest.raises(ValueError, match="no CPU path"):
+        m(torch.zeros(1, 3, 8, 8))
+
+
+def test_differentiable_reparameterisation_equals_the_reference_rule(init_golden):
+    """equivalent_kernel_bias_autograd (out-of-place, differentiable) == get_equivalent_kernel_bias, and its gradient
+    reaches all nine branches."""
+    from superresolution_amd.reprfn import RepBlock
+    torch.manual_seed(5)
+    blk = RepBlock(48, 48, "lrelu", deploy=False)
+    k0, b0 = blk.get_equivalent_kernel_bias()
+    k1, b1 = blk.equivalent_kernel_bias_autograd()
+    assert torch.allclose(k0, k1, atol=1e-7) and torch.allclose(b0, b1, atol=1e-7)
+    (k1.square().sum() + b1.square().sum()).backward()
+    for name, p in blk.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None, name
+            if name.endswith("_branch.b0"):
+                # the three fixed stencils sum to zero, so the 1x1's bias cancels out of the merged bias (up to rounding)
+                assert float(p.grad.abs().max()) <= 1e-6, name
+            else:
+                assert float(p.grad.abs().sum()) > 0, name
