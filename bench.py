@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "reprfn"])
+    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "reprfn", "memops"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg of the default workload")
     ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training leg of the default workload")
@@ -393,6 +393,26 @@ def main():
         res = run_train(args, world, rank, dev, dist)
         if rank == 0:
             print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "memops":
+        # the HBM-bound operators of the path at the 4K shapes, one launch each (tools/bench_memops.py): warp, pixel
+        # (un)shuffle, up-sampling, layout, concat, nearest down-sampling, ReLU mask, fused loss
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_memops
+        ops = bench_memops.suite(verbose=False)
+        warp = next(o for o in ops if o["op"].startswith("warp bilinear f32"))
+        if rank == 0:
+            print(json.dumps({"metric": "algorithmic GB/s of the HBM-bound operators (warp of the previous 4K output first)",
+                              "value": warp["gbps"], "unit": "GB/s", "n_gpus": 1, "steps": 10, "warmup": 3, "ms_per_step": warp["ms"],
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "backward warp of a 3-channel fp32 2160x3840 frame by per-pixel motion vectors "
+                                                     "(bilinear, align_corners=True) and the other memory-bound operators at the 4K shapes"},
+                              "roofline": {"bound": "hbm", "kernel": "sample_f32_kernel<1> (backward warp)", "achieved": warp["gbps"],
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": warp["gbps"] / HBM_PEAK_GBS, "traffic": None},
+                              "ops": ops}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return

@@ -554,14 +554,21 @@ __global__ void sample_f32_kernel(const float* __restrict__ src, const float* __
         float* d = dst + (long long)img * c * thw + pix;
         if (mode == SRHIP_BILINEAR) {
             const Taps t = make_taps(ix, iy, sw, sh);
-            const long long o00 = (long long)t.y0 * sw + t.x0;
+            // branch-free: every tap is loaded from a clamped (always valid) address and replaced by 0 when it lies
+            // outside the image, so the 4*c loads of a pixel are all in flight together; adding +0 keeps the result
+            // identical to skipping the tap
+            const int xa = t.vx0 ? t.x0 : (t.x0 < 0 ? 0 : sw - 1), xb = t.vx1 ? t.x0 + 1 : (t.x0 + 1 < 0 ? 0 : sw - 1);
+            const int ya = t.vy0 ? t.y0 : (t.y0 < 0 ? 0 : sh - 1), yb = t.vy1 ? t.y0 + 1 : (t.y0 + 1 < 0 ? 0 : sh - 1);
+            const int o00 = ya * sw + xa, o01 = ya * sw + xb, o10 = yb * sw + xa, o11 = yb * sw + xb;
+            const bool m00 = t.vy0 && t.vx0, m01 = t.vy0 && t.vx1, m10 = t.vy1 && t.vx0, m11 = t.vy1 && t.vx1;
             for (int k = 0; k < c; ++k) {
                 const float* sp = s + (long long)k * shw;
+                const float a00 = sp[o00], a01 = sp[o01], a10 = sp[o10], a11 = sp[o11];
                 float v = 0.0f;
-                if (t.vy0 && t.vx0) v = __fadd_rn(v, __fmul_rn(sp[o00], t.wnw));
-                if (t.vy0 && t.vx1) v = __fadd_rn(v, __fmul_rn(sp[o00 + 1], t.wne));
-                if (t.vy1 && t.vx0) v = __fadd_rn(v, __fmul_rn(sp[o00 + sw], t.wsw));
-                if (t.vy1 && t.vx1) v = __fadd_rn(v, __fmul_rn(sp[o00 + sw + 1], t.wse));
+                v = __fadd_rn(v, m00 ? __fmul_rn(a00, t.wnw) : 0.0f);
+                v = __fadd_rn(v, m01 ? __fmul_rn(a01, t.wne) : 0.0f);
+                v = __fadd_rn(v, m10 ? __fmul_rn(a10, t.wsw) : 0.0f);
+                v = __fadd_rn(v, m11 ? __fmul_rn(a11, t.wse) : 0.0f);
                 d[(long long)k * thw] = v;
             }
         } else {

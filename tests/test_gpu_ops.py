@@ -351,3 +351,21 @@ def test_layernorm_cf_backward_large_is_deterministic(F_):
     # dbias is a plain sum: check it against a float64 reduction
     ref = dy.double().sum(dim=(0, 2, 3))
     assert (a[2].double() - ref).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 37, 64), (1, 10, 20, 36), (1, 3, 9, 4)])
+@pytest.mark.parametrize("align", [True, False])
+def test_backward_warp_f32_out_of_frame_vectors(F_, shape, align):
+    """10 % of the motion vectors point far out of the frame: the branch-free tap loads (clamped address, tap
+    replaced by zero) must give what skipping the tap gives, i.e. the oracle's zero padding; and a repeat is
+    bit-identical."""
+    n, c, h, w = shape
+    rng = np.random.default_rng(n * 100 + c + w)
+    frame = rng.uniform(-1, 1, shape).astype(np.float32)
+    motion = (rng.standard_normal((n, 2, h, w)) * 2.5).astype(np.float32)
+    far = rng.random((n, 1, h, w)) < 0.1
+    motion = np.where(far, motion * 1e4, motion).astype(np.float32)
+    y = F_.backward_warp(dev(frame), dev(motion), "bilinear", align)
+    assert torch.equal(y, F_.backward_warp(dev(frame), dev(motion), "bilinear", align))
+    assert bool(torch.isfinite(y).all())
+    assert maxerr(y.cpu().numpy(), orc.backward_warp(frame, motion, "bilinear", align)) <= 2e-6

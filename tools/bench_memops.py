@@ -22,35 +22,47 @@ def timeit(fn, iters=10):
     return ts[len(ts) // 2]
 
 
-def line(name, ms, nbytes):
-    print(f"{name:52s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  ({nbytes / ms / 1e6 / 8000.0:5.1%} of 8 TB/s)", flush=True)
+def suite(verbose=True):
+    """-> list of {"op", "ms", "bytes", "gbps", "frac_of_hbm_peak"} (median of 10 launches each)."""
+    results = []
+
+    def line(name, ms, nbytes):
+        results.append({"op": name, "ms": ms, "bytes": nbytes, "gbps": nbytes / ms / 1e6, "frac_of_hbm_peak": nbytes / ms / 1e6 / 8000.0})
+        if verbose:
+            print(f"{name:52s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  ({nbytes / ms / 1e6 / 8000.0:5.1%} of 8 TB/s)", flush=True)
 
 
-bf = lambda *s: (torch.rand(*s, device=dev) - 0.5).to(torch.bfloat16)
-f32 = lambda *s: torch.rand(*s, device=dev)
+    bf = lambda *s: (torch.rand(*s, device=dev) - 0.5).to(torch.bfloat16)
+    f32 = lambda *s: torch.rand(*s, device=dev)
 
-# prev SR output warped by HR motion vectors (config C4): 3 channels fp32 NCHW + 2-channel motion
-fr, mv = f32(1, 3, H, W), (torch.randn(1, 2, H, W, device=dev) * 4).clamp(-32, 32)
-line("warp bilinear f32 NCHW 3ch @4K", timeit(lambda: F_.backward_warp(fr, mv, "bilinear", True)), (2 * 3 + 2) * H * W * 4)
-fr16 = bf(1, H, W, 16)
-line("warp bilinear bf16 NHWC 16ch @4K", timeit(lambda: F_.backward_warp_nhwc(fr16, mv, "bilinear", True)), 2 * 16 * H * W * 2 + 2 * H * W * 4)
-# reference-shaped LR warp: 13 channels (frames + buffers) at 540x960
-fl, ml = bf(1, h, w, 16), torch.randn(1, 2, h, w, device=dev)
-line("warp bilinear bf16 NHWC 16ch @LR", timeit(lambda: F_.backward_warp_nhwc(fl, ml, "bilinear", True)), 2 * 16 * h * w * 2 + 2 * h * w * 4)
-# network head: 48-channel LR map -> 3-channel 4K image
-head = bf(1, h, w, 48)
-line("pixel shuffle head NHWC bf16 -> NCHW f32 @4K", timeit(lambda: F_.pixel_shuffle_nhwc_to_nchw_f32(head, 3, 4)), 48 * h * w * 2 + 3 * H * W * 4)
-x = f32(1, 48, h, w)
-line("pixel shuffle f32 NCHW r=4", timeit(lambda: F_.pixel_shuffle(x, 4)), 2 * 48 * h * w * 4)
-g = f32(1, 10, H, W)
-line("pixel unshuffle f32 NCHW 10ch r=4", timeit(lambda: F_.pixel_unshuffle(g, 4)), 2 * 10 * H * W * 4)
-fm = bf(1, h, w, 32)
-line("upsample x4 bf16 NHWC 32ch -> 4K", timeit(lambda: F_.upsample_grid_bilinear_nhwc(fm, H, W)), 32 * (h * w + H * W) * 2)
-line("layout f32 NCHW 10ch -> bf16 NHWC 16ch @4K", timeit(lambda: F_.nchw_f32_to_nhwc_bf16(g)), H * W * (10 * 4 + 16 * 2))
-a, b = bf(1, H, W, 32), bf(1, H, W, 64)
-line("concat 32+64 bf16 NHWC @4K", timeit(lambda: F_.concat_nhwc(a, b)), 2 * 96 * H * W * 2)
-line("nearest down x4 f32 10ch from 4K", timeit(lambda: F_.nearest_down(g, 0.25)), 2 * 10 * h * w * 4)
-y = bf(1, H, W, 64)
-line("relu mask bf16 64ch @4K", timeit(lambda: F_.relu_mask(b, y)), 3 * 64 * H * W * 2)
-sr, tg = f32(1, 3, H, W), f32(1, 3, H, W)
-line("fused L1+SSIM fwd+bwd 3ch @4K", timeit(lambda: F_.l1_ssim_loss(sr, tg, 1.0, 0.5, 0.0, 10.0)), 11 * 3 * H * W * 4)
+    # prev SR output warped by HR motion vectors (config C4): 3 channels fp32 NCHW + 2-channel motion
+    fr, mv = f32(1, 3, H, W), (torch.randn(1, 2, H, W, device=dev) * 4).clamp(-32, 32)
+    line("warp bilinear f32 NCHW 3ch @4K", timeit(lambda: F_.backward_warp(fr, mv, "bilinear", True)), (2 * 3 + 2) * H * W * 4)
+    fr16 = bf(1, H, W, 16)
+    line("warp bilinear bf16 NHWC 16ch @4K", timeit(lambda: F_.backward_warp_nhwc(fr16, mv, "bilinear", True)), 2 * 16 * H * W * 2 + 2 * H * W * 4)
+    # reference-shaped LR warp: 13 channels (frames + buffers) at 540x960
+    fl, ml = bf(1, h, w, 16), torch.randn(1, 2, h, w, device=dev)
+    line("warp bilinear bf16 NHWC 16ch @LR", timeit(lambda: F_.backward_warp_nhwc(fl, ml, "bilinear", True)), 2 * 16 * h * w * 2 + 2 * h * w * 4)
+    # network head: 48-channel LR map -> 3-channel 4K image
+    head = bf(1, h, w, 48)
+    line("pixel shuffle head NHWC bf16 -> NCHW f32 @4K", timeit(lambda: F_.pixel_shuffle_nhwc_to_nchw_f32(head, 3, 4)), 48 * h * w * 2 + 3 * H * W * 4)
+    x = f32(1, 48, h, w)
+    line("pixel shuffle f32 NCHW r=4", timeit(lambda: F_.pixel_shuffle(x, 4)), 2 * 48 * h * w * 4)
+    g = f32(1, 10, H, W)
+    line("pixel unshuffle f32 NCHW 10ch r=4", timeit(lambda: F_.pixel_unshuffle(g, 4)), 2 * 10 * H * W * 4)
+    fm = bf(1, h, w, 32)
+    line("upsample x4 bf16 NHWC 32ch -> 4K", timeit(lambda: F_.upsample_grid_bilinear_nhwc(fm, H, W)), 32 * (h * w + H * W) * 2)
+    line("layout f32 NCHW 10ch -> bf16 NHWC 16ch @4K", timeit(lambda: F_.nchw_f32_to_nhwc_bf16(g)), H * W * (10 * 4 + 16 * 2))
+    a, b = bf(1, H, W, 32), bf(1, H, W, 64)
+    line("concat 32+64 bf16 NHWC @4K", timeit(lambda: F_.concat_nhwc(a, b)), 2 * 96 * H * W * 2)
+    line("nearest down x4 f32 10ch from 4K", timeit(lambda: F_.nearest_down(g, 0.25)), 2 * 10 * h * w * 4)
+    y = bf(1, H, W, 64)
+    line("relu mask bf16 64ch @4K", timeit(lambda: F_.relu_mask(b, y)), 3 * 64 * H * W * 2)
+    sr, tg = f32(1, 3, H, W), f32(1, 3, H, W)
+    line("fused L1+SSIM fwd+bwd 3ch @4K", timeit(lambda: F_.l1_ssim_loss(sr, tg, 1.0, 0.5, 0.0, 10.0)), 11 * 3 * H * W * 4)
+
+    return results
+
+
+if __name__ == "__main__":
+    suite()
