@@ -163,9 +163,12 @@ class ESA(nn.Module):
         f = self.conv1.out_channels
         h, w = x.shape[1:3]
         c1_ = F_.conv2d_auto(x, self.conv1.weight, self.conv1.bias, stride=1, padding=0)      # 1x1 on the MFMA kernel
-        c1 = F_.conv2d_direct(c1_, self.conv2.weight.detach(), self.conv2.bias.detach(), f, stride=2, padding=0)
+        # 3x3 / stride 2 / pad 0 = the stride-1 pad-1 layer (MFMA) at the odd pixels 2o + 1
+        full = F_.conv2d_auto(c1_, self.conv2.weight, self.conv2.bias, stride=1, padding=1)
+        ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        c1 = full[:, 1:2 * ho:2, 1:2 * wo:2, :].contiguous()
         v_max = F_.max_pool2d_nhwc(c1, 7, 3)
-        c3 = F_.conv2d_direct(v_max, self.conv3.weight.detach(), self.conv3.bias.detach(), f, stride=1, padding=1)
+        c3 = F_.conv2d_auto(v_max, self.conv3.weight, self.conv3.bias, stride=1, padding=1)
         cf = F_.conv2d_auto(c1_, self.conv_f.weight, self.conv_f.bias, stride=1, padding=0)
         s = F_.resize_bilinear_nhwc(c3, h, w, addend=cf)
         c4 = F_.conv2d_auto(s, self.conv4.weight, self.conv4.bias, stride=1, padding=0)
