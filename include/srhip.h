@@ -78,7 +78,7 @@ typedef struct {
     const void* src_b;   /* (N,H,W,cb) bf16 or NULL, cb % 16 == 0 */
     const void* wpack;   /* packed weights, see srhip_conv3x3_pack_weights */
     const float* bias;   /* fp32[cout] or NULL */
-    const void* res;     /* optional residual, (N,H,W,cout_stride) bf16 */
+    const void* res;     /* optional residual, (N,H,W,cout_stride) bf16; may equal dst (read before written) */
     void* dst;           /* (N,H,W,cout_stride) bf16, or (N,cout,H,W) fp32 if dst_nchw_f32 */
     int n, h, w;
     int ca, cb;          /* padded channel counts of src_a / src_b */
@@ -89,6 +89,10 @@ typedef struct {
     float alpha;         /* scale applied after the activation (1.0 for none) */
     int dst_nchw_f32;    /* 1: write fp32 NCHW (network output / fp32-accumulate checks); no residual */
     int res_mode;        /* srhip_res_mode: how `res` enters the epilogue */
+    int ca_stride;       /* 0, or channels per pixel of the tensor src_a points INTO (>= ca): the launch reads a
+                            channel slice [src_a, src_a + ca) of every pixel of a wider NHWC tensor (single source) */
+    int cout_w;          /* 0, or channels written per pixel (cout <= cout_w <= min(64, cout_stride), multiple of 8):
+                            dst / res point at a channel slice of a wider NHWC tensor with cout_stride channels */
 } srhip_conv3x3_args;
 
 /* Bytes of the packed-weight buffer for a (ca+cb) -> cout 3x3 layer. */

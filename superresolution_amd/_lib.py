@@ -42,7 +42,7 @@ class Conv3x3Args(ctypes.Structure):
         ("ca", c_int), ("cb", c_int),
         ("cout", c_int), ("cout_stride", c_int),
         ("act", c_int), ("slope", c_float), ("alpha", c_float),
-        ("dst_nchw_f32", c_int), ("res_mode", c_int),
+        ("dst_nchw_f32", c_int), ("res_mode", c_int), ("ca_stride", c_int), ("cout_w", c_int),
     ]
 
 

@@ -38,7 +38,9 @@ struct ConvParams {
     char* dst;
     int n, h, w;
     int ca, cb;  // padded channels of the two sources
+    int ca_stride;  // channels per pixel of the tensor src_a points into (>= ca: a channel slice of a wider tensor)
     int cout, cout_stride;
+    int cout_w;     // channels this launch writes per pixel (<= cout_stride: a channel slice of a wider tensor)
     float slope, alpha;  // slope: 1 (no activation), 0 (ReLU) or the LeakyReLU slope
     int nstrips, nsegs, seg_h, total_items;
 };
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 
     const int H = p.h, W = p.w;
     // source of sub-image s: KC == 6 is concat(A: 32 ch, B: 64 ch); KC == 3 is one 48-channel tensor
-    const int csrc0 = p.ca, csrc1 = (C::KC == 6) ? p.cb : p.ca;
+    const int csrc0 = p.ca_stride, csrc1 = (C::KC == 6) ? p.cb : p.ca_stride;
     const int choff1 = (C::KC == 3) ? 32 : 0;
 
     // pixel fragments, double buffered over taps; the buffer of (row i, tap t) is (i + t) & 1
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
         for (int k = 0; k < C::NST; ++k) {
             const int xq = x0 + 32 * pg + k * C::PPI + st_q;
             const int ch = cs * C::NCT * 32 + st_c * 8;
-            vox[k] = (xq < W && ch < p.cout_stride) ? (unsigned)((xq * p.cout_stride + ch) * 2) : kOobOffset;
+            vox[k] = (xq < W && ch < p.cout_w) ? (unsigned)((xq * p.cout_stride + ch) * 2) : kOobOffset;
         }
 
         int ring_pos = 0;  // ring slot of input row i
@@ -777,11 +779,19 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     SRHIP_REQUIRE(a->cout >= 1 && a->cout <= 64, "conv3x3: cout %d not in [1,64]", a->cout);
     SRHIP_REQUIRE(a->act == SRHIP_ACT_NONE || a->act == SRHIP_ACT_RELU || a->act == SRHIP_ACT_LRELU, "conv3x3: bad activation %d", a->act);
     SRHIP_REQUIRE((long long)a->h * a->w * 64 * 4 < (1ll << 31), "conv3x3: image too large for 32-bit offsets");
-    SRHIP_REQUIRE((long long)a->w * (a->ca > a->cb ? a->ca : a->cb) * 2 < (1ll << 31), "conv3x3: row too long");
+    const int ca_stride = a->ca_stride > 0 ? a->ca_stride : a->ca;
+    const int cout_w = a->cout_w > 0 ? a->cout_w : a->cout_stride;
+    SRHIP_REQUIRE(ca_stride >= a->ca && ca_stride % 8 == 0 && (a->cb == 0 || ca_stride == a->ca),
+                  "conv3x3: bad ca_stride %d (multiple of 8, >= ca; the two-source form takes whole tensors)", ca_stride);
+    SRHIP_REQUIRE((long long)a->w * (ca_stride > a->cb ? ca_stride : a->cb) * 2 < (1ll << 31), "conv3x3: row too long");
+    SRHIP_REQUIRE((long long)a->h * a->w * ca_stride * 2 < (1ll << 31), "conv3x3: source image too large for 32-bit offsets");
     if (a->dst_nchw_f32) {
         SRHIP_REQUIRE(a->res == nullptr, "conv3x3: fp32 NCHW output takes no residual");
     } else {
-        SRHIP_REQUIRE(a->cout_stride % 8 == 0 && a->cout_stride >= a->cout && a->cout_stride <= 64, "conv3x3: bad cout_stride %d", a->cout_stride);
+        SRHIP_REQUIRE(a->cout_stride % 8 == 0 && a->cout_stride >= a->cout, "conv3x3: bad cout_stride %d", a->cout_stride);
+        SRHIP_REQUIRE(cout_w % 8 == 0 && cout_w >= a->cout && cout_w <= 64 && cout_w <= a->cout_stride,
+                      "conv3x3: bad cout_w %d (multiple of 8, cout <= cout_w <= min(64, cout_stride))", cout_w);
+        SRHIP_REQUIRE((long long)a->h * a->w * a->cout_stride * 2 < (1ll << 31), "conv3x3: output image too large for 32-bit offsets");
     }
     ConvParams p;
     p.src_a = (const char*)a->src_a;
@@ -791,8 +801,8 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     p.res = (const char*)a->res;
     p.dst = (char*)a->dst;
     p.n = a->n; p.h = a->h; p.w = a->w;
-    p.ca = a->ca; p.cb = a->cb;
-    p.cout = a->cout; p.cout_stride = a->cout_stride;
+    p.ca = a->ca; p.cb = a->cb; p.ca_stride = ca_stride;
+    p.cout = a->cout; p.cout_stride = a->cout_stride; p.cout_w = cout_w;
     p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
     p.alpha = a->alpha;
     const int kc = (a->ca + a->cb) / 16;

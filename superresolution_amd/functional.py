@@ -79,12 +79,22 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
             src_b: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
             slope: float = 0.0, alpha: float = 1.0, out_nchw_f32: bool = False,
             cout_stride: Optional[int] = None, out: Optional[torch.Tensor] = None,
-            res_mode: int = RES_ADD) -> torch.Tensor:
+            res_mode: int = RES_ADD, ca_slice: Optional[tuple] = None, out_off: Optional[int] = None) -> torch.Tensor:
     """dst = alpha * act(conv3x3(concat(src_a, src_b)) + bias) + res   (NHWC bf16 activations);
     with ``res_mode=RES_MASK``: dst = res > 0 ? alpha * act(...) : 0;
-    with ``res_mode=RES_PRE``: dst = act(alpha * (conv + bias) + res) (partial sums of layers wider than one launch)."""
+    with ``res_mode=RES_PRE``: dst = act(alpha * (conv + bias) + res) (partial sums of layers wider than one launch).
+
+    ``ca_slice=(off, n)``: read only channels [off, off+n) of src_a (n a multiple of 16, off of 8) - no copy.
+    ``out_off=k`` (with ``out`` a wider NHWC tensor): write pad16(cout) channels at channel offset k of ``out``;
+    ``res`` (if given) is then a tensor of out's shape and is read at the same offset (it may be ``out`` itself)."""
     src_a = _req(src_a, torch.bfloat16, "src_a")
-    n, h, w, ca = src_a.shape
+    n, h, w, ca_full = src_a.shape
+    a_ptr, ca, ca_stride = src_a.data_ptr(), ca_full, 0
+    if ca_slice is not None:
+        off, ca = ca_slice
+        if src_b is not None or off % 8 or ca % 16 or off < 0 or off + ca > ca_full:
+            raise ValueError("conv3x3: bad ca_slice (single source; offset multiple of 8, width multiple of 16, inside the tensor)")
+        a_ptr, ca_stride = a_ptr + 2 * off, ca_full
     cb = 0
     if src_b is not None:
         src_b = _req(src_b, torch.bfloat16, "src_b")
@@ -93,6 +103,13 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
         cb = src_b.shape[3]
     if bias is not None:
         bias = _req(bias, torch.float32, "bias")
+    cout_w, d_off = 0, 0
+    if out_off is not None:
+        if out is None or out_nchw_f32 or out.dtype != torch.bfloat16 or not out.is_contiguous() or tuple(out.shape[:3]) != (n, h, w):
+            raise ValueError("conv3x3: out_off needs a contiguous NHWC bf16 `out` of the same (N,H,W)")
+        cout_stride, cout_w, d_off = out.shape[3], pad16(cout), 2 * out_off
+        if out_off % 8 or out_off < 0 or out_off + cout_w > cout_stride:
+            raise ValueError("conv3x3: the written channel slice must lie inside `out` at an offset that is a multiple of 8")
     if cout_stride is None:
         cout_stride = pad16(cout)
     if out_nchw_f32:
@@ -105,10 +122,10 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
             res = _req(res, torch.bfloat16, "res")
             if tuple(res.shape) != (n, h, w, cout_stride):
                 raise ValueError("conv3x3: residual shape must equal the output shape")
-    a = Conv3x3Args(src_a=src_a.data_ptr(), src_b=_ptr(src_b), wpack=wpack.data_ptr(), bias=_ptr(bias),
-                    res=_ptr(res), dst=out.data_ptr(), n=n, h=h, w=w, ca=ca, cb=cb, cout=cout,
-                    cout_stride=cout_stride, act=act, slope=slope, alpha=alpha, dst_nchw_f32=int(out_nchw_f32),
-                    res_mode=res_mode)
+    a = Conv3x3Args(src_a=a_ptr, src_b=_ptr(src_b), wpack=wpack.data_ptr(), bias=_ptr(bias),
+                    res=None if res is None else res.data_ptr() + d_off, dst=out.data_ptr() + d_off, n=n, h=h, w=w, ca=ca, cb=cb,
+                    cout=cout, cout_stride=cout_stride, act=act, slope=slope, alpha=alpha, dst_nchw_f32=int(out_nchw_f32),
+                    res_mode=res_mode, ca_stride=ca_stride, cout_w=cout_w)
     check(lib.srhip_conv3x3_fwd(a, _stream()))
     return out
 
@@ -281,8 +298,8 @@ def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
                              padding=padding, res=res, act=act, slope=slope, alpha=alpha)
     wd = weight.detach()
     bd = None if bias is None else bias.detach()
-    slices = _k_slices(cpad)
-    xs = [x] if len(slices) == 1 else [x[..., k0:k1].contiguous() for (k0, k1) in slices]
+    slices = [(k0, k1) for (k0, k1) in _k_slices(cpad) if min(k1, cin) > k0]   # drop slices that hold only channel padding
+    n_, h_, w_ = x.shape[:3]
 
     def packed(k0, k1, off, n):
         def build():
@@ -294,26 +311,24 @@ def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
             return conv3x3_pack_weights(w.float().contiguous(), w.shape[1], k1 - k0, cout=n, cout_off=off)
         return _cached_pack(weight, (k0, k1, off, n, as1x1), build)
 
+    # every launch reads its 64-channel input slice in place and writes (accumulates) its 64-channel output slice in
+    # place: no slice copies, no concat
     fuse_res = res is not None and stride == 1 and len(slices) == 1 and cout <= 64
-    outs = []
+    out = torch.empty((n_, h_, w_, pad16(cout)), dtype=torch.bfloat16, device=x.device)
+    whole_in = len(slices) == 1 and slices[0] == (0, cpad)
     for off in range(0, cout, 64):
         n = min(64, cout - off)
         b = None if bd is None else bd[off:off + n].contiguous()
-        part = None
         for i, (k0, k1) in enumerate(slices):
-            if min(k1, cin) <= k0:
-                break  # only channel padding left
-            last = i == len(slices) - 1 or min(slices[i + 1][1], cin) <= slices[i + 1][0]
+            last = i == len(slices) - 1
             wp = packed(k0, k1, off, n)
-            if part is None:
-                part = conv3x3(xs[i], wp, b, n, res=res if (fuse_res and last) else None,
-                               act=act if last else ACT_NONE, slope=slope, alpha=alpha)
+            sl = None if whole_in else (k0, k1 - k0)
+            if i == 0:
+                conv3x3(x, wp, b, n, res=res if (fuse_res and last) else None, act=act if last else ACT_NONE, slope=slope,
+                        alpha=alpha, ca_slice=sl, out=out, out_off=off)
             else:
-                part = conv3x3(xs[i], wp, None, n, res=part, res_mode=RES_PRE, act=act if last else ACT_NONE, slope=slope)
-        outs.append(part)
-    out = outs[0]
-    for o in outs[1:]:
-        out = concat_nhwc(out, o)
+                conv3x3(x, wp, None, n, res=out, res_mode=RES_PRE, act=act if last else ACT_NONE, slope=slope, ca_slice=sl,
+                        out=out, out_off=off)
     if stride == 2:
         out = max_pool2d_nhwc(out, 1, 2)  # out[i, j] = stride-1 result at (2i, 2j)
     if res is not None and not fuse_res:

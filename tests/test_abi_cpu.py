@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 def test_conv_args_struct_layout():
     from superresolution_amd._lib import Conv3x3Args
     # 6 pointers + 11 4-byte scalars, padded to pointer alignment
-    assert ctypes.sizeof(Conv3x3Args) == 6 * 8 + 12 * 4
-    assert Conv3x3Args.n.offset == 48 and Conv3x3Args.dst_nchw_f32.offset == 48 + 10 * 4 and Conv3x3Args.res_mode.offset == 92
+    assert ctypes.sizeof(Conv3x3Args) == 6 * 8 + 14 * 4
+    assert Conv3x3Args.n.offset == 48 and Conv3x3Args.dst_nchw_f32.offset == 48 + 10 * 4 and Conv3x3Args.res_mode.offset == 92 and Conv3x3Args.ca_stride.offset == 96 and Conv3x3Args.cout_w.offset == 100
 
 
 def test_packed_bytes():

@@ -75,3 +75,27 @@ def test_res_pre_mode_against_oracle():
     rn = F_.nchw_f32_to_nhwc_bf16(r.cuda())
     y = F_.conv3x3(xn, F_.conv3x3_pack_weights(wt.cuda(), 64, 64), b.cuda(), 64, res=rn, act=F_.ACT_RELU, res_mode=F_.RES_PRE)
     assert np.abs(y.permute(0, 3, 1, 2).float().cpu().numpy() - ref).max() <= 2e-2
+
+
+def test_channel_slices_in_place_equal_copies_bit_for_bit():
+    """ca_slice / out_off (a launch reading one channel slice of a wider tensor and writing one channel slice of a
+    wider tensor, with the residual read in place) against the same launches on copied slices."""
+    from superresolution_amd import functional as F_
+    g = torch.Generator(device="cuda").manual_seed(8)
+    n, h, w = 2, 37, 150
+    x = (torch.rand(n, h, w, 160, device="cuda", generator=g) - 0.4).to(torch.bfloat16)
+    wt = torch.randn(48, 64, 3, 3, device="cuda", generator=g) * 0.05
+    b = torch.randn(48, device="cuda", generator=g) * 0.1
+    wp = F_.conv3x3_pack_weights(wt, 64, 64)
+    wide = (torch.rand(n, h, w, 192, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    before = wide.clone()
+    # slice 64..128 of x -> channels 128..176 of `wide`, accumulated on what is already there (pre-activation)
+    ref = F_.conv3x3(x[..., 64:128].contiguous(), wp, b, 48, res=before[..., 128:176].contiguous(), act=F_.ACT_RELU,
+                     res_mode=F_.RES_PRE)
+    F_.conv3x3(x, wp, b, 48, res=wide, act=F_.ACT_RELU, res_mode=F_.RES_PRE, ca_slice=(64, 64), out=wide, out_off=128)
+    assert torch.equal(wide[..., 128:176], ref)
+    assert torch.equal(wide[..., :128], before[..., :128]) and torch.equal(wide[..., 176:], before[..., 176:])
+    with pytest.raises(ValueError):
+        F_.conv3x3(x, wp, b, 48, ca_slice=(100, 64))
+    with pytest.raises(ValueError):
+        F_.conv3x3(x, wp, b, 48, out=wide, out_off=160)   # 160 + pad16(48) > 192
