@@ -36,3 +36,24 @@ def test_temporal_supersampler_forward_golden():
     assert np.abs(ew.cpu().numpy() - z["enhance_weight"]).max() <= 1e-6          # mask logic: exact
     err = np.abs(sr.cpu().numpy() - z["sr"]).max()
     assert err <= 2e-2, err
+
+
+@pytest.mark.parametrize("n_history", [1, 2])
+def test_temporal_batch_equals_single_samples(n_history):
+    """Nothing couples the samples of a batch: a batch of two clips (one or two history frames) gives, per sample,
+    the result of running that clip alone; and a repeat is bit-identical."""
+    from superresolution_amd.temporal import SuperSampler
+    torch.manual_seed(7)
+    m = SuperSampler(3, 10, 4, n_history).cuda().eval()
+    g = torch.Generator().manual_seed(70 + n_history)
+    b, f, h, w = 2, n_history, 32, 48
+    args = [torch.rand(b, 3, h, w, generator=g), torch.rand(b, 10, 4 * h, 4 * w, generator=g), torch.rand(b, 10, h, w, generator=g),
+            torch.randn(b, f, 2, h, w, generator=g), torch.rand(b, f, 3, h, w, generator=g), torch.rand(b, f, 10, h, w, generator=g)]
+    run = lambda sl: m.infer(*[a[sl].clone().cuda() for a in args])
+    sr, ew = run(slice(0, 2))
+    sr2, ew2 = run(slice(0, 2))
+    assert torch.equal(sr, sr2) and torch.equal(ew, ew2)
+    assert sr.shape == (b, 3, 4 * h, 4 * w) and ew.shape == (b, 1, h, w) and bool(torch.isfinite(sr).all())
+    for i in range(b):
+        si, ei = run(slice(i, i + 1))
+        assert torch.equal(si, sr[i:i + 1]) and torch.equal(ei, ew[i:i + 1])
