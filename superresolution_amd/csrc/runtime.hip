@@ -1,4 +1,4 @@
-// Error channel, per-device immutable state (zero page, CU count) and version of libsrhip.so.
+// Error channel, per-device immutable state (CU count) and version of libsrhip.so.
 #include <mutex>
 
 #include "srhip_common.h"
@@ -26,34 +26,8 @@ int srhip_check_launch(const char* what)
 namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_mu;
-void* g_zero[kMaxDevices] = {};
 int g_cus[kMaxDevices] = {};
 }  // namespace
-
-// 4 KiB of device zeros: the source address of every out-of-image halo chunk the convolution
-// stages into LDS.  Allocated once per device, never freed, never written after the memset.
-const void* srhip_zero_page(int* status)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
-        srhip_set_error("no current HIP device");
-        *status = SRHIP_ERR_DEVICE;
-        return nullptr;
-    }
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_zero[dev]) {
-        void* p = nullptr;
-        if (hipMalloc(&p, 4096) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess ||
-            hipDeviceSynchronize() != hipSuccess) {
-            srhip_set_error("cannot allocate the zero page on device %d", dev);
-            *status = SRHIP_ERR_LAUNCH;
-            return nullptr;
-        }
-        g_zero[dev] = p;
-    }
-    *status = SRHIP_OK;
-    return g_zero[dev];
-}
 
 int srhip_num_cus()
 {

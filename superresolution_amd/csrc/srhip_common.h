@@ -36,7 +36,6 @@ __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v 
 // ---- error channel ----
 void srhip_set_error(const char* fmt, ...);
 int srhip_check_launch(const char* what);           // hipGetLastError -> status
-const void* srhip_zero_page(int* status);           // per-device 4 KiB of zeros (lazily allocated)
 int srhip_num_cus();
 
 #define SRHIP_REQUIRE(cond, ...)                      \

@@ -279,9 +279,9 @@ def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     """alpha * act(nn.Conv2d(x)) + res on an NHWC bf16 tensor with any channel count, on the MFMA kernel
     wherever the layer can be written as 3x3 / stride 1 / pad 1 launches:
 
-    * more than 64 input channels: one launch per 64-channel slice, the partial sums chained through the
-      residual input (pre-activation form on the last slice; partial sums are rounded to bf16 between launches);
-    * more than 64 output channels: one launch per 64 output channels, joined by the concat kernel;
+    * more than 64 input channels: one launch per 64-channel slice (read in place), the partial sums accumulated in
+      place through the residual input (pre-activation form; partial sums are rounded to bf16 between launches);
+    * more than 64 output channels: one launch per 64 output channels, each writing its slice of the result in place;
     * 3x3 / stride 2 / pad 1: the stride-1 layer followed by a 2x2 pick of its even pixels (same arithmetic per
       output pixel, 4x the MFMA work, still far cheaper than the vector-ALU kernel);
     * 1x1 / pad 0: the weight sits in the centre tap of a 3x3 kernel of zeros.
