@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "reprfn", "memops"])
+    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "reprfn", "reprfn_train", "memops"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg of the default workload")
     ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training leg of the default workload")
@@ -262,6 +262,67 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
     return res
 
 
+def run_reprfn_train(args, world, rank, dev, dist):
+    """Training step of RepRFN in its training form (nine branches per block, configs/trainer/4x_RepRFN.yaml) on
+    `train_batch` LR crops of (train_crop/4)^2 per GPU: forward + L1 + backward + gradient all-reduce + AdamW."""
+    from superresolution_amd import RepRFN
+    from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters
+    B, S = args.train_batch, args.train_crop // SCALE
+    torch.manual_seed(42)
+    model = RepRFN().to(dev).train()
+    broadcast_parameters(model, src=0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = FlatGradAllReducer(params)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(42 + rank)
+    x = torch.rand(B, 3, S, S, generator=g).to(dev)
+    target = torch.rand(B, 3, S * SCALE, S * SCALE, generator=g).to(dev)
+
+    def step():
+        red.zero_grad()
+        loss = (model(x) - target).abs().mean()
+        loss.backward()
+        red.all_reduce()
+        opt.step()
+        return loss.detach()
+
+    loss0 = float(step())
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(loss)) and float(loss) < loss0 and bool(torch.isfinite(red.flat).all())
+    if rank != 0:
+        return None
+    ms = dt / args.steps * 1e3
+    # deploy-form convolution FLOPs per LR pixel (0.404 TFLOP per 540x960 frame), x3 for forward + both gradients
+    flop_step = 3.0 * 0.40421293056e12 / (LR_H * LR_W) * B * S * S
+    tflops = flop_step / 1e12 / (ms * 1e-3)
+    return {"metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs", "value": world * B * args.steps / dt,
+            "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"RepRFN(3,3,48,4) training form, {B} LR crops of {S}x{S} (HR {S * SCALE}x{S * SCALE}) per GPU: forward + L1 + "
+                                   "backward + gradient all-reduce + AdamW, fp32 master weights", "crops_per_step_per_gpu": B,
+                       "tflop_per_step_per_gpu": flop_step / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "whole step (merged-kernel convolution FLOPs, forward + data + weight gradients, "
+                         "over the wall time of a step)", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None}}
+
+
 class _FlopCounter:
     """Algorithmic convolution FLOPs of one forward pass, counted at the operator boundary (2 * Cout * Cin * kh * kw
     per output pixel with the layer's REAL kernel size and stride; the extra work of composed launches is not
@@ -413,6 +474,14 @@ def main():
                               "roofline": {"bound": "hbm", "kernel": "sample_f32_kernel<1> (backward warp)", "achieved": warp["gbps"],
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": warp["gbps"] / HBM_PEAK_GBS, "traffic": None},
                               "ops": ops}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "reprfn_train":
+        res = run_reprfn_train(args, world, rank, dev, dist)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
