@@ -187,7 +187,7 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
     model = make_model(dev).train()
     broadcast_parameters(model, src=0)
     red = FlatGradAllReducer(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)  # configs/trainer/4x_H2.yaml:12-17
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)  # configs/trainer/4x_H2.yaml:12-17
     loss_group = FusedLossGroup(1.0, 0.5, clip=(0.0, 10.0), report=False)  # clip: core/trainer.py:154-156
     g = torch.Generator().manual_seed(42 + rank)
     alias = torch.rand(B, 1, 3, S, S, generator=g).to(dev)
@@ -273,7 +273,7 @@ def run_reprfn_train(args, world, rank, dev, dist):
     broadcast_parameters(model, src=0)
     params = [p for p in model.parameters() if p.requires_grad]
     red = FlatGradAllReducer(params)
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)
     g = torch.Generator().manual_seed(42 + rank)
     x = torch.rand(B, 3, S, S, generator=g).to(dev)
     target = torch.rand(B, 3, S * SCALE, S * SCALE, generator=g).to(dev)
