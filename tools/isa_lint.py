@@ -7,7 +7,8 @@ data only arrives after the hand-placed s_waitcnt.  The sources therefore pass e
 fence right behind its wait, which prints `; srhip-fence <registers>` into the assembly.  This script
 compiles the given .hip files to gfx950 assembly and verifies, on every control-flow path, that between an
 asm load and the fence of its destination registers NO instruction reads or writes those registers (a
-register move there would copy stale data; a re-use would be overwritten when the load lands).
+register move there would copy stale data; a re-use would be overwritten when the load lands).  It also checks
+that no VALU instruction overwrites the data registers of a 96/128-bit store directly behind it.
 
 usage: isa_lint.py [--keep DIR] file.hip [file.hip ...]      exit status 1 when a violation is found
 """
@@ -119,6 +120,32 @@ def lint_function(name, body):
                     continue
             for s in successors(j):
                 stack.append((s, pend))
+    # Second check: a store of more than 64 bits reads its data registers after it has issued; the instruction right
+    # behind it must not overwrite them (the compiler's hazard table has exempted one store form before).
+    store_re = re.compile(r"^(buffer|global|flat|scratch)_store_dwordx[34]\s+(.*)$")
+    for i, (kind, code, _) in enumerate(insts):
+        if kind != "inst":
+            continue
+        m = store_re.match(code)
+        if not m:
+            continue
+        ops = [o.strip() for o in m.group(2).split(",")]
+        data = regs_of(ops[0] if m.group(1) == "buffer" else ops[1] if len(ops) > 1 else "")
+        waited = 0
+        for j in range(i + 1, min(i + 4, len(insts))):
+            k2, c2, _ = insts[j]
+            if k2 != "inst":
+                continue
+            op = c2.split()[0]
+            if op == "s_nop":
+                waited += int(c2.split()[1]) + 1
+                continue
+            if op.startswith(("s_", "buffer_", "global_", "ds_")) or waited >= 2:
+                break
+            dst = regs_of(c2.split(",")[0])
+            if op.startswith("v_") and dst & data:
+                problems.append((i, code, j, c2, sorted(dst & data)))
+            break
     return n_loads, problems
 
 
