@@ -107,7 +107,7 @@ def roofline_block(kernel, flop, nbytes, avg_ms, med_ms, launches, traffic):
     tflops = flop / (avg_ms * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_unit": "bytes/launch (profiles/r1_e_conv64_pmc.csv)" if traffic is not None else None,
+            "traffic_unit": "bytes/launch (profiles/r1_g_conv64_pmc.csv)" if traffic is not None else None,
             "avg_launch_ms": avg_ms, "median_launch_ms": med_ms, "launches_timed": launches,
             "algorithmic_bytes_per_launch": nbytes, "algorithmic_flop_per_launch": flop,
             "mfma_view": {"achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -118,7 +118,7 @@ def measured_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed counter passes (separate
     FETCH_SIZE and WRITE_SIZE runs, KiB units; FETCH_SIZE doubled as gfx950 tallies the 128-byte
     requests of wide streaming reads at 64 bytes).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_e_conv64_pmc.csv")
+    path = os.path.join(ROOT, "profiles", "r1_g_conv64_pmc.csv")
     try:
         vals = {}
         for line in open(path):
