@@ -18,6 +18,7 @@ convolution at 4K: 21 of the 25 HR layers), timed per launch with events on the 
 `cpu_baseline` times the CPU oracle on a bounded crop of the same workload on the host cores.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -38,6 +39,14 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense
 HBM_PEAK_GBS = 8000.0
 # The dominant kernel (64->64 3x3, bf16 NHWC in and out) moves 2 x 128 B per pixel for 73,728 FLOP: 288 FLOP/B,
 # under the machine balance of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, so HBM bandwidth is the roofline that bounds it.
+
+
+def settle_host():
+    """Called right before a timed region: collect garbage once and move every live object out of the collector's
+    generations, so that no full collection (80-110 ms in a process that has imported torch) lands inside the timed
+    steps.  The collector stays enabled; a training script does the same after building its model."""
+    gc.collect()
+    gc.freeze()
 
 
 def parse():
@@ -211,6 +220,7 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
     loss0 = float(step().detach())
     for _ in range(max(warmup - 1, 0)):
         step()
+    settle_host()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -289,6 +299,7 @@ def run_reprfn_train(args, world, rank, dev, dist):
     loss0 = float(step())
     for _ in range(max(args.warmup - 1, 0)):
         step()
+    settle_host()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -399,6 +410,7 @@ def run_aux_infer(args, world, rank, dev, dist):
             first = step().clone()
         for _ in range(args.warmup):
             step()
+        settle_host()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -503,6 +515,7 @@ def main():
     first = step().clone()  # the timed frames must reproduce it bit for bit (same inputs)
     for _ in range(args.warmup):
         step()
+    settle_host()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -275,12 +275,19 @@ SRHIP_API int srhip_disocclusion_f32(const float* cur_frame, const float* cur_bu
  *   lrelu_mask:        dst = dy * (y > 0 ? 1 : slope)
  *   sigmoid_gate_bwd:  y = x * sigmoid(gate)  ->  dx = dy * sig, dgate = dy * x * sig * (1 - sig)
  *   max_pool2d_bwd:    src (N,h,w,c) the pooled input, dy (N,ho,wo,c) -> dx (N,h,w,c); first maximum wins a tie
+ *   max_pool2d_arg / max_pool2d_bwd_arg: the same pair for a training step.  The forward also writes, per output
+ *                      element, the window position ky*k+kx of its maximum into arg (N,ho,wo,c) uint8 (k <= 15), and the
+ *                      backward gathers from arg and dy alone (what autograd's max_pool2d_with_indices keeps, :298)
  *   resize_bilinear_bwd: dy (N,ho,wo,c) -> dx (N,h,w,c), adjoint of srhip_resize_bilinear_nhwc */
 SRHIP_API int srhip_lrelu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, float slope, void* stream);
 SRHIP_API int srhip_sigmoid_gate_bwd_bf16(const void* x, const void* gate, const void* dy, void* dx, void* dgate, size_t count,
                                           void* stream);
 SRHIP_API int srhip_max_pool2d_bwd_nhwc(const void* src, const void* dy, void* dx, int n, int c, int h, int w, int k, int s,
                                         void* stream);
+SRHIP_API int srhip_max_pool2d_arg_nhwc(const void* src, void* dst, void* arg, int n, int c, int h, int w, int k, int s,
+                                        void* stream);
+SRHIP_API int srhip_max_pool2d_bwd_arg_nhwc(const void* arg, const void* dy, void* dx, int n, int c, int h, int w, int k, int s,
+                                            void* stream);
 SRHIP_API int srhip_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int n, int c, int h, int w, int ho, int wo,
                                              int align_corners, void* stream);
 

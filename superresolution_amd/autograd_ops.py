@@ -87,14 +87,15 @@ def sigmoid_gate(x: Tensor, gate: Tensor) -> Tensor:
 class _MaxPool(Function):
     @staticmethod
     def forward(ctx, x: Tensor, k: int, s: int):
-        ctx.save_for_backward(x)
-        ctx.k, ctx.s = k, s
-        return F_.max_pool2d_nhwc(x, k, s)
+        y, arg = F_.max_pool2d_arg_nhwc(x, k, s)
+        ctx.save_for_backward(arg)
+        ctx.k, ctx.s, ctx.hw = k, s, tuple(x.shape[1:3])
+        return y
 
     @staticmethod
     def backward(ctx, dy: Tensor):
-        (x,) = ctx.saved_tensors
-        return F_.max_pool2d_bwd_nhwc(x, dy.contiguous(), ctx.k, ctx.s), None, None
+        (arg,) = ctx.saved_tensors
+        return F_.max_pool2d_bwd_arg_nhwc(arg, dy.contiguous(), ctx.hw[0], ctx.hw[1], ctx.k, ctx.s), None, None
 
 
 def max_pool2d(x: Tensor, k: int, s: int) -> Tensor:

@@ -412,6 +412,70 @@ __global__ void max_pool_bwd_nhwc_kernel(const unsigned short* __restrict__ src,
         *(uint4*)(dx + (((long long)img * h + y) * w + x) * c + g * 8) = pack8(acc);
     }
 }
+// max_pool2d(k, s) that also records, per output element, which window position (ky * k + kx) supplied the maximum
+// (the first one in scan order; a NaN wins like in max_pool_nhwc_kernel).  One byte per element: k * k <= 255.
+__global__ void max_pool_arg_nhwc_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                         unsigned char* __restrict__ arg, int n, int c, int h, int w, int ho, int wo, int k, int s)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * ho * wo * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int ox = (int)(p % wo); p /= wo;
+        const int oy = (int)(p % ho);
+        const int img = (int)(p / ho);
+        float m[8];
+        unsigned int a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; a[e] = 0u; }
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx) {
+                float v[8];
+                unpack8(*(const uint4*)(src + (((long long)img * h + oy * s + ky) * w + ox * s + kx) * c + g * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; a[e] = (unsigned int)(ky * k + kx); }
+            }
+        const long long o = (((long long)img * ho + oy) * wo + ox) * c + g * 8;
+        *(uint4*)(dst + o) = pack8(m);
+        *(uint2*)(arg + o) = make_uint2(a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24), a[4] | (a[5] << 8) | (a[6] << 16) | (a[7] << 24));
+    }
+}
+// Backward of the above from the recorded positions, gather form (deterministic, no atomics): an input pixel sums dy
+// of the windows that cover it and named it.
+__global__ void max_pool_bwd_arg_nhwc_kernel(const unsigned char* __restrict__ arg, const unsigned short* __restrict__ dy,
+                                             unsigned short* __restrict__ dx, int n, int c, int h, int w, int ho, int wo, int k, int s)
+{
+    const int cg = c / 8;
+    const long long total = (long long)n * h * w * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int x = (int)(p % w); p /= w;
+        const int y = (int)(p % h);
+        const int img = (int)(p / h);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+        const int oy_lo = y - k + 1 > 0 ? (y - k + 1 + s - 1) / s : 0, oy_hi = y / s < ho - 1 ? y / s : ho - 1;
+        const int ox_lo = x - k + 1 > 0 ? (x - k + 1 + s - 1) / s : 0, ox_hi = x / s < wo - 1 ? x / s : wo - 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const long long o = (((long long)img * ho + oy) * wo + ox) * c + g * 8;
+                const uint2 a = *(const uint2*)(arg + o);
+                const unsigned int mine = (unsigned int)((y - oy * s) * k + (x - ox * s));
+                float d[8];
+                unpack8(*(const uint4*)(dy + o), d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned int ae = ((e < 4 ? a.x : a.y) >> (8 * (e & 3))) & 0xffu;
+                    if (ae == mine) acc[e] += d[e];
+                }
+            }
+        *(uint4*)(dx + (((long long)img * h + y) * w + x) * c + g * 8) = pack8(acc);
+    }
+}
 // bilinear resize backward, gather form: source pixel (y, x) sums w_y * w_x * dy over the output pixels whose
 // four taps include it.  The tap positions and weights replay the forward kernel's arithmetic.
 __device__ __forceinline__ void resize_taps(int o, int n_in, float scale, int align, int& i0, int& i1, float& l)
@@ -1319,6 +1383,30 @@ SRHIP_API int srhip_max_pool2d_bwd_nhwc(const void* src, const void* dy, void* d
     hipLaunchKernelGGL(max_pool_bwd_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const unsigned short*)src, (const unsigned short*)dy, (unsigned short*)dx, n, c, h, w, ho, wo, k, s);
     return srhip_check_launch("max_pool2d_bwd_nhwc");
+}
+
+SRHIP_API int srhip_max_pool2d_arg_nhwc(const void* src, void* dst, void* arg, int n, int c, int h, int w, int k, int s, void* stream)
+{
+    SRHIP_REQUIRE(src && dst && arg, "max_pool2d_arg_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && k >= 1 && k <= 15 && s >= 1 && h >= k && w >= k,
+                  "max_pool2d_arg_nhwc: bad shape (c %% 8 == 0, k <= 15, window inside the image)");
+    const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
+    const long long work = (long long)n * ho * wo * (c / 8);
+    hipLaunchKernelGGL(max_pool_arg_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, (unsigned short*)dst, (unsigned char*)arg, n, c, h, w, ho, wo, k, s);
+    return srhip_check_launch("max_pool2d_arg_nhwc");
+}
+
+SRHIP_API int srhip_max_pool2d_bwd_arg_nhwc(const void* arg, const void* dy, void* dx, int n, int c, int h, int w, int k, int s,
+                                            void* stream)
+{
+    SRHIP_REQUIRE(arg && dy && dx, "max_pool2d_bwd_arg_nhwc: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && k >= 1 && k <= 15 && s >= 1 && h >= k && w >= k, "max_pool2d_bwd_arg_nhwc: bad shape");
+    const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
+    const long long work = (long long)n * h * w * (c / 8);
+    hipLaunchKernelGGL(max_pool_bwd_arg_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const unsigned char*)arg, (const unsigned short*)dy, (unsigned short*)dx, n, c, h, w, ho, wo, k, s);
+    return srhip_check_launch("max_pool2d_bwd_arg_nhwc");
 }
 
 SRHIP_API int srhip_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int n, int c, int h, int w, int ho, int wo,

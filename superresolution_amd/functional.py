@@ -660,6 +660,30 @@ def max_pool2d_bwd_nhwc(x: torch.Tensor, dy: torch.Tensor, k: int, s: int) -> to
     return dx
 
 
+def max_pool2d_arg_nhwc(x: torch.Tensor, k: int, s: int):
+    """max_pool2d_nhwc that also returns the window position of every maximum ((N,ho,wo,C) uint8), for the backward."""
+    x = _req(x, torch.bfloat16, "x")
+    n, h, w, c = x.shape
+    if not 1 <= k <= 15:
+        raise ValueError("max_pool2d_arg_nhwc: window size must be 1..15")
+    shape = (n, (h - k) // s + 1, (w - k) // s + 1, c)
+    out = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+    arg = torch.empty(shape, dtype=torch.uint8, device=x.device)
+    check(lib.srhip_max_pool2d_arg_nhwc(x.data_ptr(), out.data_ptr(), arg.data_ptr(), n, c, h, w, k, s, _stream()))
+    return out, arg
+
+
+def max_pool2d_bwd_arg_nhwc(arg: torch.Tensor, dy: torch.Tensor, h: int, w: int, k: int, s: int) -> torch.Tensor:
+    """Gradient of the (N,h,w,C) pooled input from the recorded positions and dy (both (N,ho,wo,C))."""
+    arg, dy = _req(arg, torch.uint8, "arg"), _req(dy, torch.bfloat16, "dy")
+    n, ho, wo, c = dy.shape
+    if tuple(arg.shape) != tuple(dy.shape) or (ho, wo) != ((h - k) // s + 1, (w - k) // s + 1):
+        raise ValueError("max_pool2d_bwd_arg_nhwc: arg / dy do not have the pooled shape")
+    dx = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=dy.device)
+    check(lib.srhip_max_pool2d_bwd_arg_nhwc(arg.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, c, h, w, k, s, _stream()))
+    return dx
+
+
 def resize_bilinear_bwd_nhwc(dy: torch.Tensor, h: int, w: int, align_corners: bool = False) -> torch.Tensor:
     """Adjoint of resize_bilinear_nhwc: dy (N,ho,wo,C) -> gradient of the (N,h,w,C) source."""
     dy = _req(dy, torch.bfloat16, "dy")

@@ -61,6 +61,22 @@ class SeqConv3x3(nn.Module):
         return k, b
 
 
+_IDENT = {}
+
+
+def _identity_kernel(out_channels: int, in_channels: int, device, dtype) -> Tensor:
+    """The identity branch as a 3x3 kernel (RepRFN.py:236-241): 1 at the centre tap of channel i -> i.  Built once per
+    shape and device (constant; building it per step would put an index write into every training step)."""
+    key = (out_channels, in_channels, str(device), dtype)
+    hit = _IDENT.get(key)
+    if hit is None:
+        hit = torch.zeros(out_channels, in_channels, 3, 3, device=device, dtype=dtype)
+        idx = torch.arange(min(in_channels, out_channels), device=device)
+        hit[idx, idx, 1, 1] = 1.0
+        _IDENT[key] = hit
+    return hit
+
+
 class RepBlock(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, act_type: str = "lrelu", deploy: bool = False) -> None:
         super().__init__()
@@ -112,10 +128,7 @@ class RepBlock(nn.Module):
              + pad(self.rbr_1x3_branch.weight, (0, 0, 1, 1)) + pad(self.rbr_3x1_branch.weight, (1, 1, 0, 0))
              + torch.einsum("omyx,mi->oiyx", self.rbr_1x1_3x3_branch_3x3.weight, self.rbr_1x1_3x3_branch_1x1.weight[:, :, 0, 0]))
         b = self.rbr_3x3_branch.bias + self.rbr_1x1_branch.bias + self.rbr_1x3_branch.bias + self.rbr_3x1_branch.bias
-        ident = torch.zeros_like(k)
-        idx = torch.arange(min(self.in_channels, self.out_channels), device=k.device)
-        ident[idx, idx, 1, 1] = 1.0
-        k = k + ident
+        k = k + _identity_kernel(self.out_channels, self.in_channels, k.device, k.dtype)
         for seq in (self.rbr_conv1x1_sbx_branch, self.rbr_conv1x1_sby_branch, self.rbr_conv1x1_lpl_branch):
             sk, sb = seq.rep_params()
             k = k + sk
@@ -146,6 +159,36 @@ class RepBlock(nn.Module):
             hit = (tag, self.get_equivalent_kernel_bias())
             object.__setattr__(self, "_eq_cache", hit)
         return hit[1]
+
+
+def merged_kernels_autograd(blocks) -> list:
+    """``equivalent_kernel_bias_autograd`` of several RepBlocks of one shape at once: the branch tensors are stacked
+    and the weight algebra runs once on the stack, so a training step launches a few dozen small kernels for it instead
+    of a few dozen per block.  Returns [(kernel, bias)] in the order of ``blocks``; same operations, same values."""
+    blocks = list(blocks)
+    if not blocks:
+        return []
+    shape = (blocks[0].in_channels, blocks[0].out_channels)
+    if any(b.deploy for b in blocks) or any((b.in_channels, b.out_channels) != shape for b in blocks) or len(blocks) == 1:
+        return [b.equivalent_kernel_bias_autograd() for b in blocks]
+    pad = torch.nn.functional.pad
+
+    def st(get):
+        return torch.stack([get(b) for b in blocks])
+
+    k = (st(lambda b: b.rbr_3x3_branch.weight) + pad(st(lambda b: b.rbr_1x1_branch.weight), (1, 1, 1, 1))
+         + pad(st(lambda b: b.rbr_1x3_branch.weight), (0, 0, 1, 1)) + pad(st(lambda b: b.rbr_3x1_branch.weight), (1, 1, 0, 0))
+         + torch.einsum("nomyx,nmi->noiyx", st(lambda b: b.rbr_1x1_3x3_branch_3x3.weight),
+                        st(lambda b: b.rbr_1x1_3x3_branch_1x1.weight)[:, :, :, 0, 0]))
+    bias = (st(lambda b: b.rbr_3x3_branch.bias) + st(lambda b: b.rbr_1x1_branch.bias)
+            + st(lambda b: b.rbr_1x3_branch.bias) + st(lambda b: b.rbr_3x1_branch.bias))
+    k = k + _identity_kernel(shape[1], shape[0], k.device, k.dtype)
+    for name in ("rbr_conv1x1_sbx_branch", "rbr_conv1x1_sby_branch", "rbr_conv1x1_lpl_branch"):
+        # SeqConv3x3.rep_params on the stack
+        dw = (st(lambda b: getattr(b, name).scale) * st(lambda b: getattr(b, name).mask))[:, :, 0]       # (N,O,3,3)
+        k = k + dw[:, :, None, :, :] * st(lambda b: getattr(b, name).k0)[:, :, :, 0, 0][:, :, :, None, None]
+        bias = bias + st(lambda b: getattr(b, name).b0) * dw.sum(dim=(2, 3)) + st(lambda b: getattr(b, name).bias)
+    return list(zip(k.unbind(0), bias.unbind(0)))
 
 
 class ESA(nn.Module):
@@ -252,11 +295,13 @@ class RepRFN(nn.Module):
         x = F_.nchw_f32_to_nhwc_bf16(inputs.detach().float())
         fea = A.conv3x3(x, self.fea_conv.weight, self.fea_conv.bias, cout_stride=cs)
         out = fea
+        merged = merged_kernels_autograd(getattr(getattr(self, f"reprfb{bi}"), f"repblock{ri}")
+                                         for bi in range(1, 5) for ri in range(1, 4))
         for bi in range(1, 5):
             rfb = getattr(self, f"reprfb{bi}")
             t = out
             for ri in range(1, 4):
-                k, b = getattr(rfb, f"repblock{ri}").equivalent_kernel_bias_autograd()
+                k, b = merged[(bi - 1) * 3 + ri - 1]
                 t = A.conv3x3(t, k, b, act=F_.ACT_LRELU, slope=_SLOPE, cout_stride=cs)
             t = A.add(A.conv3x3(t, rfb.conv3.weight, rfb.conv3.bias, act=F_.ACT_LRELU, slope=_SLOPE, cout_stride=cs), out)
             out = _esa_train(rfb.esa, t)

@@ -45,6 +45,12 @@ def test_max_pool_backward_matches_autograd(shape, k, s):
     y.backward(dy)
     got = _nchw(F_.max_pool2d_bwd_nhwc(_nhwc(x.detach()), _nhwc(dy), k, s))
     assert (got - x.grad).abs().max() <= 2e-2 * max(1.0, float(x.grad.abs().max()))
+    # the pair that records the positions in the forward: same pooled values, same gradient, bit for bit
+    y2, arg = F_.max_pool2d_arg_nhwc(_nhwc(x.detach()), k, s)
+    assert torch.equal(y2, F_.max_pool2d_nhwc(_nhwc(x.detach()), k, s)) and torch.equal(_nchw(y2), y.detach())
+    assert arg.dtype == torch.uint8 and int(arg.max()) < k * k
+    got2 = F_.max_pool2d_bwd_arg_nhwc(arg, _nhwc(dy), shape[2], shape[3], k, s)
+    assert torch.equal(_nchw(got2), got)
 
 
 @pytest.mark.parametrize("small,big", [((5, 7), (23, 31)), ((1, 3), (20, 28)), ((9, 13), (40, 56)), ((6, 6), (6, 6))])
