@@ -105,6 +105,43 @@ __global__ void nchw_f32_to_nhwc_bf16_generic_kernel(const float* __restrict__ s
     }
 }
 
+// The same conversion staged through LDS: a block takes 64 consecutive pixels, reads every channel plane with the pixel
+// index fastest (coalesced 256-byte runs) and writes the 64 * cpad * 2 contiguous output bytes in linear order, 16 bytes
+// per lane.  Row stride in LDS is padded to an odd number of 16-byte entries.
+constexpr int kLayoutTile = 64;
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_tiled_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                         int n, int c, long long hw, int cpad)
+{
+    extern __shared__ uint4 tile[];
+    const int cg = cpad / 8, cgp = cg | 1;
+    const long long total = (long long)n * hw;
+    const long long ntiles = (total + kLayoutTile - 1) / kLayoutTile;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long p0 = t * kLayoutTile;
+        const int npx = (int)(total - p0 < kLayoutTile ? total - p0 : kLayoutTile);
+        for (int it = threadIdx.x; it < kLayoutTile * cg; it += blockDim.x) {
+            const int px = it & (kLayoutTile - 1), g = it / kLayoutTile;
+            if (px < npx) {
+                const long long p = p0 + px;
+                const long long img = p / hw, pix = p - img * hw;
+                const float* sp = src + img * c * hw + pix;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (g * 8 + k < c) ? sp[(long long)(g * 8 + k) * hw] : 0.0f;
+                tile[px * cgp + g] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            }
+        }
+        __syncthreads();
+        uint4* out = (uint4*)(dst + p0 * cpad);
+        for (int it = threadIdx.x; it < npx * cg; it += blockDim.x) {
+            const int px = it / cg, g = it - px * cg;
+            out[it] = tile[px * cgp + g];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst,
                                              int n, int c, long long hw, int cstride)
 {
@@ -560,6 +597,27 @@ __global__ void gradient_map_kernel(const float* __restrict__ src, float* __rest
             }
         dst[i] = sqrtf(gv * gv + gh * gh + eps);
     }
+}
+
+// The same map on a (column block, row, plane) grid: 32-bit index arithmetic, no division per element.
+__global__ void gradient_map_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, float eps)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (x >= w) return;
+    const int y = (int)blockIdx.y;
+    const float* pl = src + (long long)blockIdx.z * h * w;
+    float gv = 0.0f, gh = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+            const float v = pl[yy * w + xx];
+            gv += (float)(ky - 1) * v;
+            gh += (float)(kx - 1) * v;
+        }
+    dst[(long long)blockIdx.z * h * w + y * w + x] = sqrtf(gv * gv + gh * gh + eps);
 }
 
 __global__ void warp_nhwc_kernel(const unsigned short* __restrict__ frame, const float* __restrict__ motion,
@@ -1107,6 +1165,13 @@ SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, in
         case 64: hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<64>, dim3(g), dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw); break;
         default:
             SRHIP_REQUIRE(cpad % 8 == 0, "nchw_f32_to_nhwc_bf16: cpad must be a multiple of 8 (got %d)", cpad);
+            if ((size_t)kLayoutTile * ((cpad / 8) | 1) * sizeof(uint4) <= 48 * 1024) {
+                const long long ntiles = ((long long)n * hw + kLayoutTile - 1) / kLayoutTile;
+                const long long cap = (long long)srhip_num_cus() * 16;
+                hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_tiled_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256),
+                                   (size_t)kLayoutTile * ((cpad / 8) | 1) * sizeof(uint4), s, src, (unsigned short*)dst, n, c, hw, cpad);
+                break;
+            }
             hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_generic_kernel, dim3(grid_for((long long)n * hw * (cpad / 8), srhip_num_cus())),
                                dim3(kThreads), 0, s, src, (unsigned short*)dst, n, c, hw, cpad);
             break;
@@ -1424,8 +1489,12 @@ SRHIP_API int srhip_gradient_map_f32(const float* src, float* dst, int planes, i
 {
     SRHIP_REQUIRE(src && dst, "gradient_map_f32: null pointer");
     SRHIP_REQUIRE(planes >= 1 && h >= 1 && w >= 1, "gradient_map_f32: bad shape");
-    hipLaunchKernelGGL(gradient_map_kernel, dim3(grid_for((long long)planes * h * w, srhip_num_cus())), dim3(kThreads), 0,
-                       (hipStream_t)stream, src, dst, (long long)planes, h, w, eps);
+    if (h <= 65535 && planes <= 65535 && (long long)h * w < (1ll << 31))
+        hipLaunchKernelGGL(gradient_map_rows_kernel, dim3(srhip_div_up(w, kThreads), h, planes), dim3(kThreads), 0,
+                           (hipStream_t)stream, src, dst, h, w, eps);
+    else
+        hipLaunchKernelGGL(gradient_map_kernel, dim3(grid_for((long long)planes * h * w, srhip_num_cus())), dim3(kThreads), 0,
+                           (hipStream_t)stream, src, dst, (long long)planes, h, w, eps);
     return srhip_check_launch("gradient_map_f32");
 }
 

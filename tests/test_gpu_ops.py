@@ -73,6 +73,21 @@ def test_layout_roundtrip_bit_exact(F_, c):
     assert np.array_equal(back, x)
 
 
+@pytest.mark.parametrize("c,shape", [(96, (2, 7, 13)), (112, (1, 16, 16)), (160, (3, 5, 43)), (384, (1, 9, 8)), (100, (2, 1, 1))])
+def test_layout_wide_channel_counts_bit_exact(F_, c, shape):
+    """Channel counts of the temporal network's unshuffled buffers (core/models/model_final.py:95-105) go through the
+    LDS-tiled kernel (64-pixel tiles: partial tiles, tiles that straddle two images) or, above 368 channels, the plain one."""
+    n, h, w = shape
+    rng = np.random.default_rng(c + h)
+    x = bf16r(rng.standard_normal((n, c, h, w)))
+    y = F_.nchw_f32_to_nhwc_bf16(dev(x))
+    cp = (c + 15) // 16 * 16
+    assert y.shape == (n, h, w, cp)
+    ref = np.zeros(y.shape, np.float32)
+    ref[..., :c] = np.transpose(x, (0, 2, 3, 1))
+    assert np.array_equal(y.float().cpu().numpy(), ref)
+
+
 # ------------------------------------------------------------------------------------------------
 # MFMA convolution vs goldens
 # ------------------------------------------------------------------------------------------------

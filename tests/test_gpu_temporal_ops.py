@@ -35,6 +35,9 @@ def test_gradient_map_golden(F_, z):
     rng = np.random.default_rng(1)
     x = rng.random((3, 6, 40, 57), dtype=np.float32)
     assert np.abs(F_.gradient_map(dev(x)).cpu().numpy() - orc.gradient_map(x)).max() <= 2e-6
+    for shape in [(1, 1, 1, 1), (2, 3, 1, 300), (1, 2, 301, 1), (1, 1, 5, 257)]:     # single rows / columns, a row wider than a block
+        x = rng.random(shape, dtype=np.float32)
+        assert np.abs(F_.gradient_map(dev(x)).cpu().numpy() - orc.gradient_map(x)).max() <= 2e-6
 
 
 @pytest.mark.parametrize("name", ["t64_64", "t192_192"])
