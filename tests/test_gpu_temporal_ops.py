@@ -35,7 +35,7 @@ def test_gradient_map_golden(F_, z):
     rng = np.random.default_rng(1)
     x = rng.random((3, 6, 40, 57), dtype=np.float32)
     assert np.abs(F_.gradient_map(dev(x)).cpu().numpy() - orc.gradient_map(x)).max() <= 2e-6
-    for shape in [(1, 1, 1, 1), (2, 3, 1, 300), (1, 2, 301, 1), (1, 1, 5, 257)]:     # single rows / columns, a row wider than a block
+    for shape in [(1, 1, 1, 1), (2, 3, 1, 300), (1, 2, 301, 1), (1, 1, 5, 257), (2, 2, 9, 4), (1, 3, 33, 1028)]:   # single rows / columns, rows wider than a block, both kernels
         x = rng.random(shape, dtype=np.float32)
         assert np.abs(F_.gradient_map(dev(x)).cpu().numpy() - orc.gradient_map(x)).max() <= 2e-6
 
