@@ -291,6 +291,14 @@ SRHIP_API int srhip_max_pool2d_bwd_arg_nhwc(const void* arg, const void* dy, voi
 SRHIP_API int srhip_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int n, int c, int h, int w, int ho, int wo,
                                              int align_corners, void* stream);
 
+/* Gated sum of the temporal network's main stage (core/models/model_final.py:422):
+ *   dst = cur + sigmoid(f_self * g_cross) * fmap + sigmoid(g_self * f_cross) * grad
+ * cur / fmap / grad / dst (pixels, c) bf16 NHWC, the four gates one bf16 value per pixel read at pixel * gate_stride
+ * elements (the 1-channel attention outputs live in 16-channel padded maps); fp32 arithmetic, one rounding at the end. */
+SRHIP_API int srhip_attention_fuse_bf16(const void* cur, const void* fmap, const void* grad, const void* f_self, const void* g_cross,
+                                        const void* g_self, const void* f_cross, int gate_stride, void* dst, size_t pixels, int c,
+                                        void* stream);
+
 /* Second half of nn.ConvTranspose2d(k=2, s=2) (core/models/model_final.py:198-203) written as a 1x1 convolution to
  * 4*C channels: src (N,h,w,4C) bf16 with channel (i*2+j)*C + c  ->  dst (N,2h,2w,C), dst[2y+i][2x+j][c]. */
 SRHIP_API int srhip_depth_to_space2_nhwc(const void* src, void* dst, int n, int h, int w, int c, void* stream);

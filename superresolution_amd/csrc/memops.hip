@@ -373,6 +373,26 @@ __global__ void sigmoid_gate_kernel(const uint4* __restrict__ x, const uint4* __
         dst[i] = pack8(a);
     }
 }
+// dst = cur + sigmoid(f_self * g_cross) * fmap + sigmoid(g_self * f_cross) * grad with one gate value per pixel
+// (core/models/model_final.py:422): NHWC bf16 maps of c channels, gates read at pixel * gate_stride, fp32 arithmetic.
+__global__ void attention_fuse_kernel(const uint4* __restrict__ cur, const uint4* __restrict__ fmap, const uint4* __restrict__ grad,
+                                      const unsigned short* __restrict__ f_self, const unsigned short* __restrict__ g_cross,
+                                      const unsigned short* __restrict__ g_self, const unsigned short* __restrict__ f_cross,
+                                      int gate_stride, uint4* __restrict__ dst, long long nvec, int cg)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const long long px = i / cg;
+        const float wf = 1.0f / (1.0f + expf(-(bf16_bits_to_f32(f_self[px * gate_stride]) * bf16_bits_to_f32(g_cross[px * gate_stride]))));
+        const float wg = 1.0f / (1.0f + expf(-(bf16_bits_to_f32(g_self[px * gate_stride]) * bf16_bits_to_f32(f_cross[px * gate_stride]))));
+        float a[8], b[8], c[8];
+        unpack8(cur[i], a);
+        unpack8(fmap[i], b);
+        unpack8(grad[i], c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = __fadd_rn(__fadd_rn(a[e], __fmul_rn(wf, b[e])), __fmul_rn(wg, c[e]));
+        dst[i] = pack8(a);
+    }
+}
 
 // ---- backward kernels of the ESA block and of LeakyReLU (autograd of core/arch/RepRFN.py:295-308,17-33) ----
 // dst = dy * (y > 0 ? 1 : slope): backward of (Leaky)ReLU from its OUTPUT (slope > 0 keeps the sign)
@@ -1451,6 +1471,21 @@ SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst
     hipLaunchKernelGGL(sigmoid_gate_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4*)x, (const uint4*)gate, (uint4*)dst, nvec);
     return srhip_check_launch("sigmoid_gate_bf16");
+}
+
+SRHIP_API int srhip_attention_fuse_bf16(const void* cur, const void* fmap, const void* grad, const void* f_self, const void* g_cross,
+                                        const void* g_self, const void* f_cross, int gate_stride, void* dst, size_t pixels, int c,
+                                        void* stream)
+{
+    SRHIP_REQUIRE(cur && fmap && grad && f_self && g_cross && g_self && f_cross && dst, "attention_fuse_bf16: null pointer");
+    SRHIP_REQUIRE(c >= 8 && c % 8 == 0 && gate_stride >= 1, "attention_fuse_bf16: c must be a multiple of 8, gate_stride >= 1");
+    if (pixels == 0) return SRHIP_OK;
+    const long long nvec = (long long)pixels * (c / 8);
+    hipLaunchKernelGGL(attention_fuse_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)cur, (const uint4*)fmap, (const uint4*)grad, (const unsigned short*)f_self,
+                       (const unsigned short*)g_cross, (const unsigned short*)g_self, (const unsigned short*)f_cross, gate_stride,
+                       (uint4*)dst, nvec, c / 8);
+    return srhip_check_launch("attention_fuse_bf16");
 }
 
 SRHIP_API int srhip_lrelu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, float slope, void* stream)

@@ -660,6 +660,25 @@ def max_pool2d_bwd_nhwc(x: torch.Tensor, dy: torch.Tensor, k: int, s: int) -> to
     return dx
 
 
+def attention_fuse(cur: torch.Tensor, fmap: torch.Tensor, grad: torch.Tensor, f_self: torch.Tensor, g_cross: torch.Tensor,
+                   g_self: torch.Tensor, f_cross: torch.Tensor) -> torch.Tensor:
+    """cur + sigmoid(f_self * g_cross) * fmap + sigmoid(g_self * f_cross) * grad (core/models/model_final.py:422).
+    cur / fmap / grad: (N,H,W,C) bf16 contiguous; the gates: (N,H,W,1) bf16 views of maps with one common channel stride."""
+    cur, fmap, grad = _req(cur, torch.bfloat16, "cur"), _req(fmap, torch.bfloat16, "fmap"), _req(grad, torch.bfloat16, "grad")
+    if fmap.shape != cur.shape or grad.shape != cur.shape:
+        raise ValueError("attention_fuse: cur, fmap and grad must have one shape")
+    n, h, w, c = cur.shape
+    gates = (f_self, g_cross, g_self, f_cross)
+    gs = gates[0].stride(2)
+    for t in gates:
+        if t.dtype != torch.bfloat16 or not t.is_cuda or tuple(t.shape) != (n, h, w, 1) or t.stride() != (h * w * gs, w * gs, gs, 1):
+            raise ValueError("attention_fuse: every gate must be a (N,H,W,1) bf16 view with pixel stride %d" % gs)
+    out = torch.empty_like(cur)
+    check(lib.srhip_attention_fuse_bf16(cur.data_ptr(), fmap.data_ptr(), grad.data_ptr(), f_self.data_ptr(), g_cross.data_ptr(),
+                                        g_self.data_ptr(), f_cross.data_ptr(), gs, out.data_ptr(), n * h * w, c, _stream()))
+    return out
+
+
 def max_pool2d_arg_nhwc(x: torch.Tensor, k: int, s: int):
     """max_pool2d_nhwc that also returns the window position of every maximum ((N,ho,wo,C) uint8), for the backward."""
     x = _req(x, torch.bfloat16, "x")

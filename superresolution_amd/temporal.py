@@ -205,10 +205,8 @@ class MainNetwork(nn.Module):
         gmap = F_.pixel_unshuffle(F_.gradient_map(grad_in, self.grad_map[0].eps), self.sr_scale)
         grad, g_self, g_cross = self.attn_grad.run(F_.nchw_f32_to_nhwc_bf16(gmap))
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
-        # model_final.py:422 (element-wise, channel-broadcast gates)
-        cur = fmap_current.float() + torch.sigmoid(f_self.float() * g_cross.float()) * fmap.float() \
-            + torch.sigmoid(g_self.float() * f_cross.float()) * grad.float()
-        cur = cur.to(torch.bfloat16)
+        # model_final.py:422 (element-wise, channel-broadcast gates), one kernel
+        cur = F_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)
         return self.main_network.run(F_.concat_nhwc(F_.concat_nhwc(cur, fmap_history), fmap_gbuffer))
 
 

@@ -139,3 +139,22 @@ def test_depth_to_space_is_a_permutation(F_):
     check(lib.srhip_depth_to_space2_nhwc(src.data_ptr(), dst.data_ptr(), n, h, w, c, torch.cuda.current_stream().cuda_stream))
     ref = src.view(n, h, w, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, c)
     assert torch.equal(dst, ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 7, 64), (2, 9, 4, 32)])
+def test_attention_fuse_matches_the_reference_formula(F_, shape):
+    """model_final.py:422 on bf16 maps with fp32 arithmetic: the fused kernel against the torch expression."""
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(c)
+    cur, fmap, grad = (torch.randn(n, h, w, c, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    gates = [(torch.randn(n, h, w, 16, generator=g) * 2).to(torch.bfloat16).cuda()[..., 0:1] for _ in range(4)]
+    f_self, g_cross, g_self, f_cross = gates
+    ref = cur.float() + torch.sigmoid(f_self.float() * g_cross.float()) * fmap.float() \
+        + torch.sigmoid(g_self.float() * f_cross.float()) * grad.float()
+    got = F_.attention_fuse(cur, fmap, grad, f_self, g_cross, g_self, f_cross)
+    assert got.shape == cur.shape and got.dtype == torch.bfloat16
+    # one bf16 rounding of an fp32 result whose sigmoid may differ from torch's by an ulp
+    assert (got.float() - ref).abs().max().item() <= 2e-2
+    assert (got.float() - ref.to(torch.bfloat16).float()).abs().gt(0).float().mean().item() <= 0.01
+    with pytest.raises(ValueError):
+        F_.attention_fuse(cur, fmap, grad, f_self.contiguous(), g_cross, g_self, f_cross)
