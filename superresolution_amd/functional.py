@@ -233,11 +233,15 @@ def conv_transpose2x2s2_auto(x: torch.Tensor, weight: torch.Tensor, bias: Option
     return out
 
 
-def gradient_map(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
-    """GradientMap (core/models/model_final.py:160-187) on an fp32 (N,C,H,W) tensor."""
+def gradient_map(x: torch.Tensor, eps: float = 1e-6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GradientMap (core/models/model_final.py:160-187) on an fp32 (N,C,H,W) tensor; `out` may be a contiguous
+    slice of a larger tensor (every plane is processed on its own)."""
     x = _req(x, torch.float32, "x")
     n, c, h, w = x.shape
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.dtype != torch.float32 or out.shape != x.shape or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("gradient_map: out must be a contiguous fp32 tensor of x's shape on x's device")
     check(lib.srhip_gradient_map_f32(x.data_ptr(), out.data_ptr(), n * c, h, w, eps, _stream()))
     return out
 

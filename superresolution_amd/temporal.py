@@ -100,15 +100,31 @@ class GBuffersEncoder(nn.Module):
         r2 = self.factor ** 2
         folded = F_.pixel_unshuffle(buffer, self.factor)               # channel c*r2 + i*r + j
         # normal (0:3), base colour (6:9) and depth (9:10) planes, folded
-        enh = torch.cat((folded[:, 0:3 * r2], folded[:, 6 * r2:9 * r2], folded[:, 9 * r2:10 * r2]), dim=1).contiguous()
-        fmap = _run_seq(self.conv_main, F_.nchw_f32_to_nhwc_bf16(folded))
-        e = F_.nchw_f32_to_nhwc_bf16(enh)
+        fn = F_.nchw_f32_to_nhwc_bf16(folded)
+        fmap = _run_seq(self.conv_main, fn)
+        # picked from the converted map (the conversion rounds element by element, so the order does not matter)
+        if r2 % 2 == 0 and fn.shape[-1] % 2 == 0:      # copy channel pairs as 32-bit words
+            f32 = fn.view(torch.int32)
+            e = torch.cat((f32[..., 0:3 * r2 // 2], f32[..., 3 * r2:5 * r2]), dim=-1).view(torch.bfloat16)
+        else:
+            e = torch.cat((fn[..., 0:3 * r2], fn[..., 6 * r2:10 * r2]), dim=-1)
         for m in list(self.conv_enhance)[:-1]:
             e = m.run(e)
         last = self.conv_enhance[-1][0]
         # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
         return F_.conv2d_auto(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU,
-                              alpha=float(self.enhance_param), res=fmap)
+                              alpha=self._enhance_scale(), res=fmap)
+
+    def _enhance_scale(self) -> float:
+        """enhance_param as a host number, read from the device only when the parameter changed (reading it per
+        frame would wait for the launch queue to drain)."""
+        p = self.enhance_param
+        tag = (p._version, p.data_ptr())
+        hit = getattr(self, "_enhance_cache", None)
+        if hit is None or hit[0] != tag:
+            hit = (tag, float(p))
+            object.__setattr__(self, "_enhance_cache", hit)
+        return hit[1]
 
 
 class HistoryRefiner(nn.Module):
@@ -201,8 +217,13 @@ class MainNetwork(nn.Module):
         self.main_network = FusionNetwork(basic_channels + hist_channels + gbuffer_channels, basic_channels + gbuffer_channels)
 
     def run(self, fmap_current: Tensor, fmap_history: Tensor, fmap_gbuffer: Tensor, hr_buffer: Tensor) -> Tensor:
-        grad_in = torch.cat((hr_buffer[:, 0:3], hr_buffer[:, 6:9]), dim=1).contiguous()
-        gmap = F_.pixel_unshuffle(F_.gradient_map(grad_in, self.grad_map[0].eps), self.sr_scale)
+        # normal and base-colour planes (model_final.py:417); each range is contiguous per sample, so no copy is made
+        nb, _, hh, ww = hr_buffer.shape
+        gfull = torch.empty((nb, 6, hh, ww), dtype=torch.float32, device=hr_buffer.device)
+        for i in range(nb):
+            F_.gradient_map(hr_buffer[i:i + 1, 0:3], self.grad_map[0].eps, out=gfull[i:i + 1, 0:3])
+            F_.gradient_map(hr_buffer[i:i + 1, 6:9], self.grad_map[0].eps, out=gfull[i:i + 1, 3:6])
+        gmap = F_.pixel_unshuffle(gfull, self.sr_scale)
         grad, g_self, g_cross = self.attn_grad.run(F_.nchw_f32_to_nhwc_bf16(gmap))
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
         # model_final.py:422 (element-wise, channel-broadcast gates), one kernel
