@@ -16,7 +16,13 @@ from torch import Tensor
 
 
 class FlatGradAllReducer:
-    def __init__(self, params: Iterable[Tensor], process_group=None) -> None:
+    """``gather=False`` (default): every ``p.grad`` is a view of the bucket all the time and backward accumulates into
+    it in place (one small add kernel per parameter).  ``gather=True`` is for networks with hundreds of small
+    parameters (RepRFN's training form has 264): ``zero_grad`` drops the gradients, backward hands each parameter its
+    gradient tensor without a copy, and ``all_reduce`` first moves them all into the bucket with one multi-tensor copy
+    and re-points ``p.grad`` at the views, so that the optimiser still reads the bucket."""
+
+    def __init__(self, params: Iterable[Tensor], process_group=None, gather: bool = False) -> None:
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGradAllReducer: no trainable parameters")
@@ -25,9 +31,12 @@ class FlatGradAllReducer:
             raise ValueError("FlatGradAllReducer: parameters must share one device and dtype")
         self.group = process_group
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self.gather = gather
+        self.views: List[Tensor] = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            p.grad = None if gather else self.views[-1]
             off += p.numel()
 
     @property
@@ -35,8 +44,28 @@ class FlatGradAllReducer:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def zero_grad(self) -> None:
-        """Replaces ``optimizer.zero_grad()``: keeps the views, zeroes the bucket."""
-        self.flat.zero_()
+        """Replaces ``optimizer.zero_grad()``: keeps the views and zeroes the bucket, or (gather mode) drops the
+        gradients so that backward assigns instead of accumulating."""
+        if self.gather:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat.zero_()
+
+    def collect(self) -> None:
+        """Gather mode: move the gradients backward produced into the bucket (parameters without one get zeros)."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is v:
+                continue
+            if p.grad is None:
+                v.zero_()
+            else:
+                src.append(p.grad)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def check_views(self) -> None:
         base = self.flat.untyped_storage().data_ptr()
@@ -47,6 +76,8 @@ class FlatGradAllReducer:
 
     def all_reduce(self) -> None:
         """Average the gradients over the ranks (call after backward, before optimizer.step)."""
+        if self.gather:
+            self.collect()
         w = self.world_size
         if w == 1:
             return

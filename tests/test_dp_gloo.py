@@ -93,3 +93,31 @@ def test_flat_bucket_views_and_single_rank_noop():
     lin.zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError):
         red.check_views()
+
+
+def test_gather_mode_fills_the_same_bucket():
+    """gather=True: backward assigns the gradients, all_reduce() moves them into the bucket in one copy; the bucket,
+    the optimiser's view of it and a second accumulation behave like the in-place mode."""
+    from superresolution_amd.dp import FlatGradAllReducer
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+    net_b = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+    net_b.load_state_dict(net_a.state_dict())
+    unused = torch.nn.Parameter(torch.ones(2))
+    ra = FlatGradAllReducer(list(net_a.parameters()))
+    rb = FlatGradAllReducer(list(net_b.parameters()) + [unused], gather=True)
+    x = torch.randn(6, 5)
+    for _ in range(2):                      # the second round checks zero_grad / re-pointing
+        ra.zero_grad(); rb.zero_grad()
+        assert all(p.grad is None for p in rb.params)
+        net_a(x).square().sum().backward()
+        net_b(x).square().sum().backward()
+        net_b(2 * x).sum().backward()       # accumulation over two backward passes before the collect
+        net_a(2 * x).sum().backward()
+        ra.all_reduce(); rb.all_reduce()
+        rb.check_views()
+        n = ra.flat.numel()
+        assert torch.allclose(rb.flat[:n], ra.flat, rtol=1e-6, atol=1e-7)
+        assert torch.equal(rb.flat[n:], torch.zeros(2))
+        rb.all_reduce()                     # idempotent: nothing left to collect
+        assert torch.allclose(rb.flat[:n], ra.flat, rtol=1e-6, atol=1e-7)
