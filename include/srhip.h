@@ -291,6 +291,13 @@ SRHIP_API int srhip_max_pool2d_bwd_arg_nhwc(const void* arg, const void* dy, voi
 SRHIP_API int srhip_resize_bilinear_bwd_nhwc(const void* dy, void* dx, int n, int c, int h, int w, int ho, int wo,
                                              int align_corners, void* stream);
 
+/* dilate_velocity (core/tools/math.py:80-100): motion (B,H,W,2) fp32, depth (B,1,H,W) fp32 -> dst (B,H,W,2): every
+ * pixel takes the motion vector of the pixel with the smallest depth in its ksize x ksize neighbourhood.  As in the
+ * reference the neighbourhood is zero-padded (F.unfold), the first minimum in row-major window order wins and the
+ * chosen position is clamped to the frame.  Bit-exact (index arithmetic and a copy). */
+SRHIP_API int srhip_dilate_velocity_f32(const float* motion, const float* depth, float* dst, int b, int h, int w, int ksize,
+                                        void* stream);
+
 /* Gated sum of the temporal network's main stage (core/models/model_final.py:422):
  *   dst = cur + sigmoid(f_self * g_cross) * fmap + sigmoid(g_self * f_cross) * grad
  * cur / fmap / grad / dst (pixels, c) bf16 NHWC, the four gates one bf16 value per pixel read at pixel * gate_stride

@@ -534,6 +534,34 @@ ORC_API void orc_clamp_depth(const float* src, float* dst, long long n, float th
     }
 }
 
+/* core/tools/math.py:80-100: every pixel takes the motion vector of the pixel with the smallest depth in its
+ * k x k neighbourhood.  The neighbourhood is read through F.unfold's ZERO padding (a border pixel sees depth 0 outside
+ * the frame), the first minimum in row-major window order wins, the chosen position is clamped to the frame.
+ * motion (B,H,W,2), depth (B,1,H,W) -> out (B,H,W,2). */
+ORC_API void orc_dilate_velocity(const float* motion, const float* depth, float* out, int B, int H, int W, int k)
+{
+    const int r = k / 2;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float best = 0.0f;
+                int pos = -1;
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx) {
+                        const int yy = y + ky - r, xx = x + kx - r;
+                        const float v = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0.0f : depth[((size_t)b * H + yy) * W + xx];
+                        if (pos < 0 || v < best || (v != v && best == best)) { best = v; pos = ky * k + kx; }
+                    }
+                int sx = x + pos % k - r, sy = y + pos / k - r;
+                sx = sx < 0 ? 0 : (sx > W - 1 ? W - 1 : sx);
+                sy = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy);
+                const float* m = motion + (((size_t)b * H + sy) * W + sx) * 2;
+                float* o = out + (((size_t)b * H + y) * W + x) * 2;
+                o[0] = m[0];
+                o[1] = m[1];
+            }
+}
+
 /* ------------------------------------------------------------------------- */
 /* Pieces used only by the RepRFN ESA block (core/arch/RepRFN.py:295-308):      */
 /* max_pool2d(k,s) without padding, bilinear resize align_corners=False.        */

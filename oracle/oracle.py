@@ -221,6 +221,15 @@ def clamp_depth(depth, thres1=3.0, thres2=7.0):
     return out
 
 
+def dilate_velocity(motion, depth, ksize=3):
+    """core/tools/math.py:80-100 per sample: motion (B,H,W,2), depth (B,1,H,W) -> (B,H,W,2)."""
+    motion, depth = _c(motion), _c(depth)
+    B, H, W, _ = motion.shape
+    out = np.empty_like(motion)
+    lib().orc_dilate_velocity(_p(motion), _p(depth), _p(out), _i(B), _i(H), _i(W), _i(ksize))
+    return out
+
+
 def load_and_augment(arrays, crop=None, hflip=False, vflip=False, velocity=False):
     """core/data/supersampling_sequence.py:153-200 on already-loaded `arr_0` arrays (fp16 CHW): crop (x1, y1, x2, y2),
     the two flips (hflip reverses axis 1, vflip axis 2), the motion-vector sign fix, cast to fp32, stack."""

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "srhip_lrelu_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "srhip_sigmoid_gate_bwd_bf16": (c_int, [c_void_p] * 5 + [c_size_t, c_void_p]),
     "srhip_max_pool2d_bwd_nhwc": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "srhip_dilate_velocity_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "srhip_attention_fuse_bf16": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "srhip_max_pool2d_arg_nhwc": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "srhip_max_pool2d_bwd_arg_nhwc": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),

@@ -619,6 +619,28 @@ __global__ void gradient_map_kernel(const float* __restrict__ src, float* __rest
     }
 }
 
+// core/tools/math.py:80-100: each pixel takes the motion vector of the pixel with the smallest depth in its k x k
+// neighbourhood (zero outside the frame, as F.unfold pads; first minimum in window order; position clamped to the frame).
+__global__ void dilate_velocity_kernel(const float2* __restrict__ motion, const float* __restrict__ depth, float2* __restrict__ dst,
+                                       int h, int w, int k)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (x >= w) return;
+    const int y = (int)blockIdx.y, r = k / 2;
+    const float* dp = depth + (long long)blockIdx.z * h * w;
+    float best = 0.0f;
+    int pos = -1;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) {
+            const int yy = y + ky - r, xx = x + kx - r;
+            const float v = (yy < 0 || yy >= h || xx < 0 || xx >= w) ? 0.0f : dp[yy * w + xx];
+            if (pos < 0 || v < best || (v != v && best == best)) { best = v; pos = ky * k + kx; }
+        }
+    const int sx = min(max(x + pos % k - r, 0), w - 1), sy = min(max(y + pos / k - r, 0), h - 1);
+    const long long base = (long long)blockIdx.z * h * w;
+    dst[base + y * w + x] = motion[base + sy * w + sx];
+}
+
 // The same map on a (column block, row, plane) grid: 32-bit index arithmetic, no division per element.
 __global__ void gradient_map_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, float eps)
 {
@@ -1574,6 +1596,19 @@ SRHIP_API int srhip_gradient_map_f32(const float* src, float* dst, int planes, i
         hipLaunchKernelGGL(gradient_map_kernel, dim3(grid_for((long long)planes * h * w, srhip_num_cus())), dim3(kThreads), 0,
                            (hipStream_t)stream, src, dst, (long long)planes, h, w, eps);
     return srhip_check_launch("gradient_map_f32");
+}
+
+SRHIP_API int srhip_dilate_velocity_f32(const float* motion, const float* depth, float* dst, int b, int h, int w, int ksize,
+                                        void* stream)
+{
+    SRHIP_REQUIRE(motion && depth && dst, "dilate_velocity_f32: null pointer");
+    SRHIP_REQUIRE(b >= 1 && b <= 65535 && h >= 1 && h <= 65535 && w >= 1 && (long long)h * w < (1ll << 30),
+                  "dilate_velocity_f32: bad shape (at most 65535 rows and samples)");
+    SRHIP_REQUIRE(ksize >= 1 && ksize % 2 == 1 && ksize <= 15, "dilate_velocity_f32: ksize must be odd, 1..15");
+    SRHIP_REQUIRE(((size_t)motion | (size_t)dst) % 8 == 0, "dilate_velocity_f32: motion and dst must be 8-byte aligned");
+    hipLaunchKernelGGL(dilate_velocity_kernel, dim3(srhip_div_up(w, kThreads), h, b), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const float2*)motion, depth, (float2*)dst, h, w, ksize);
+    return srhip_check_launch("dilate_velocity_f32");
 }
 
 SRHIP_API int srhip_concat_nhwc(const void* a, const void* b, void* dst, size_t pixels, int ca, int cb, void* stream)

@@ -664,6 +664,20 @@ def max_pool2d_bwd_nhwc(x: torch.Tensor, dy: torch.Tensor, k: int, s: int) -> to
     return dx
 
 
+def dilate_velocity(motion: torch.Tensor, depth: torch.Tensor, ksize: int = 3) -> torch.Tensor:
+    """core/tools/math.py:80-100: motion (B,H,W,2) fp32, depth (B,1,H,W) fp32 -> (B,H,W,2), the motion vector of the
+    nearest-depth pixel of every ksize x ksize neighbourhood."""
+    motion, depth = _req(motion, torch.float32, "motion"), _req(depth, torch.float32, "depth")
+    if motion.dim() != 4 or motion.shape[-1] != 2:
+        raise ValueError("dilate_velocity: motion must be (B,H,W,2)")
+    b, h, w, _ = motion.shape
+    if tuple(depth.shape) != (b, 1, h, w):
+        raise ValueError("dilate_velocity: depth must be (B,1,H,W) with motion's B, H, W")
+    out = torch.empty_like(motion)
+    check(lib.srhip_dilate_velocity_f32(motion.data_ptr(), depth.data_ptr(), out.data_ptr(), b, h, w, ksize, _stream()))
+    return out
+
+
 def attention_fuse(cur: torch.Tensor, fmap: torch.Tensor, grad: torch.Tensor, f_self: torch.Tensor, g_cross: torch.Tensor,
                    g_self: torch.Tensor, f_cross: torch.Tensor) -> torch.Tensor:
     """cur + sigmoid(f_self * g_cross) * fmap + sigmoid(g_self * f_cross) * grad (core/models/model_final.py:422).

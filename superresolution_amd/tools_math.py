@@ -8,6 +8,10 @@ names, argument order, defaults and error behaviour:
   * ``backward_warping_history(...)`` -- core/models/model_final.py:17-37 (motion accumulation over
     the history, then warping of frames and buffers).
   * ``make_coord(shape, ranges=None, acquire_batch_dim=True, dtype, device)`` -- core/tools/math.py:107-130.
+  * ``dilate_velocity(motion, depth, ksize=3)`` -- core/tools/math.py:80-100 (nothing in the reference calls it; its
+    final ``motion[:, y_idx, x_idx, :]`` indexes every sample with every sample's positions and returns
+    (B,B,1,H,W,2) instead of the documented shape).  The mirror gathers per sample and returns (B,H,W,2), which for
+    B = 1 holds exactly the reference's values.
 
 Tensors are fp32 NCHW on the GPU, as the reference passes them.  The bilinear warp is
 differentiable (frame and motion gradients through the scatter-add backward kernel).
@@ -68,3 +72,9 @@ def make_coord(shape: Tuple[int, int], ranges: Optional[Any] = None, acquire_bat
     h, w = shape
     coord = F_.make_coord(h, w, device)
     return coord if acquire_batch_dim else coord[0]
+
+
+def dilate_velocity(motion: Tensor, depth: Tensor, ksize: int = 3) -> Tensor:
+    """motion (B,H,W,2), depth (B,1,H,W) -> (B,H,W,2): each pixel's motion vector replaced by that of the nearest-depth
+    pixel in its ksize x ksize neighbourhood (zero-padded depth, first minimum wins, position clamped to the frame)."""
+    return F_.dilate_velocity(motion.float(), depth.float(), ksize)

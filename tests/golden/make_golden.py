@@ -445,6 +445,24 @@ def gen_temporal_masks():
     np.savez_compressed(os.path.join(OUT, "temporal_masks.npz"), **out)
 
 
+def gen_dilate_velocity():
+    """core/tools/math.py:80-100 run as it stands on single-sample inputs (for B = 1 its advanced indexing yields
+    (1,1,1,h,w,2): the gathered motion of every pixel) -> tests/golden/dilate_velocity.npz."""
+    from core.tools.math import dilate_velocity
+    g = torch.Generator().manual_seed(123)
+    out = {}
+    for tag, (h, w, k) in {"a": (9, 13, 3), "b": (6, 5, 5), "c": (1, 7, 3)}.items():
+        motion = torch.randn(1, h, w, 2, generator=g)
+        # depth well above zero in the interior and quantised, so that ties occur; the zero padding of F.unfold wins at
+        # the border, as in the reference
+        depth = (torch.rand(1, 1, h, w, generator=g) * 6).round() / 2 + 0.5
+        ref = dilate_velocity(motion, depth, k)
+        assert ref.shape == (1, 1, 1, h, w, 2)
+        out[f"{tag}.motion"], out[f"{tag}.depth"], out[f"{tag}.k"] = motion.numpy(), depth.numpy(), np.int32(k)
+        out[f"{tag}.out"] = ref.reshape(1, h, w, 2).numpy()
+    np.savez_compressed(os.path.join(OUT, "dilate_velocity.npz"), **out)
+
+
 def gen_feeder():
     """Sample loading of the reference (core/data/supersampling_sequence.py:153-200): fp16 CHW `arr_0` arrays, crop,
     flips (with the motion-vector sign fix), cast to fp32, stacked over the clip -> tests/golden/feeder.npz.
@@ -550,6 +568,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "reprfn_train":
         gen_reprfn_train()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dilate_velocity":
+        gen_dilate_velocity()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "feeder":
         gen_feeder()
         sys.exit(0)
@@ -571,4 +592,5 @@ if __name__ == "__main__":
     gen_temporal_ops()
     gen_temporal_masks()
     gen_feeder()
+    gen_dilate_velocity()
     gen_temporal_model()

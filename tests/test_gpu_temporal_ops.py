@@ -158,3 +158,20 @@ def test_attention_fuse_matches_the_reference_formula(F_, shape):
     assert (got.float() - ref.to(torch.bfloat16).float()).abs().gt(0).float().mean().item() <= 0.01
     with pytest.raises(ValueError):
         F_.attention_fuse(cur, fmap, grad, f_self.contiguous(), g_cross, g_self, f_cross)
+
+
+def test_dilate_velocity_bit_exact(F_):
+    """srhip_dilate_velocity_f32 against the reference function's own outputs and, at other shapes (batch, a row wider
+    than a block, 7x7 window), against the oracle."""
+    from superresolution_amd.tools_math import dilate_velocity
+    zz = np.load(os.path.join(os.path.dirname(__file__), "golden", "dilate_velocity.npz"))
+    for tag in ("a", "b", "c"):
+        got = dilate_velocity(dev(zz[f"{tag}.motion"]), dev(zz[f"{tag}.depth"]), int(zz[f"{tag}.k"])).cpu().numpy()
+        assert np.array_equal(got, zz[f"{tag}.out"]), tag
+    rng = np.random.default_rng(8)
+    for (b, h, w, k) in [(2, 11, 300, 3), (3, 5, 4, 7), (1, 1, 1, 3)]:
+        m = rng.standard_normal((b, h, w, 2)).astype(np.float32)
+        d = (np.round(rng.random((b, 1, h, w)) * 6) / 2 + 0.5).astype(np.float32)
+        assert np.array_equal(F_.dilate_velocity(dev(m), dev(d), k).cpu().numpy(), orc.dilate_velocity(m, d, k))
+    with pytest.raises(ValueError):
+        F_.dilate_velocity(dev(m), dev(d[:, :, :0]), 3)

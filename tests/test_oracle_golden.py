@@ -209,3 +209,17 @@ def test_layernorm_cf_backward_oracle_vs_torch_autograd():
         _close(dx, z[f"{tag}.dx"], 1e-5)
         _close(dw, z[f"{tag}.dw"], 1e-5 * max(1.0, float(np.abs(z[f"{tag}.dw"]).max())))
         _close(db, z[f"{tag}.db"], 1e-5 * max(1.0, float(np.abs(z[f"{tag}.db"]).max())))
+
+
+def test_dilate_velocity_matches_the_reference_function():
+    """core/tools/math.py:80-100 run on single samples (tests/golden/dilate_velocity.npz): ties, borders where the
+    zero padding of F.unfold wins, a one-row frame, 3x3 and 5x5 windows -- bit-exact."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "dilate_velocity.npz"))
+    for tag in ("a", "b", "c"):
+        got = orc.dilate_velocity(z[f"{tag}.motion"], z[f"{tag}.depth"], int(z[f"{tag}.k"]))
+        assert np.array_equal(got, z[f"{tag}.out"]), tag
+    # samples of a batch are independent
+    m = np.concatenate([z["a.motion"], z["a.motion"][:, ::-1].copy()])
+    d = np.concatenate([z["a.depth"], z["a.depth"][:, :, ::-1].copy()])
+    both = orc.dilate_velocity(m, d, 3)
+    assert np.array_equal(both[0:1], z["a.out"]) and np.array_equal(both[1:2], orc.dilate_velocity(m[1:2], d[1:2], 3))
