@@ -15,6 +15,31 @@ from ._lib import check, lib
 
 KEYS = ("anti-alias", "alias", "buffers", "velocity")
 
+# Channel layout of the 10-channel G-buffer array every `buffers` file holds (tools/ue_data.json:14-29, merged in this
+# order by tools/data_preprocess.py:66-81): name -> (first channel, one past the last).
+GBUFFER_SCHEMA = {"WorldNormal": (0, 3), "Metallic": (3, 4), "Specular": (4, 5), "Roughness": (5, 6), "BaseColor": (6, 9),
+                  "SceneDepth": (9, 10)}
+
+
+def merge_gbuffers(planes: Dict[str, np.ndarray]) -> np.ndarray:
+    """Already-decoded render targets (name -> (>=channels,H,W) RGB-ordered CHW array) -> the (10,H,W) G-buffer array in
+    GBUFFER_SCHEMA order, keeping the first `channels` planes of each (tools/data_preprocess.py:66-81)."""
+    missing = [k for k in GBUFFER_SCHEMA if k not in planes]
+    if missing:
+        raise KeyError(f"merge_gbuffers: missing render targets {missing}")
+    return np.concatenate([np.asarray(planes[k])[: hi - lo] for k, (lo, hi) in GBUFFER_SCHEMA.items()], axis=0)
+
+
+def decode_motion_vector(rgb: np.ndarray) -> np.ndarray:
+    """The engine's velocity target, decoded to RGB-ordered CHW with values in [0, 1], -> (2,H,W) motion in pixels
+    (tools/data_preprocess.py:50-63): channel 0 = -(R - 0.5) * W/2, channel 1 = (G - 0.5) * H/2."""
+    v = np.array(np.asarray(rgb)[:2], dtype=np.float32) - np.float32(0.5)
+    h, w = v.shape[-2:]
+    v[0] = -v[0]
+    v[0] = v[0] * (w / 2)
+    v[1] = v[1] * (h / 2)
+    return v
+
 
 def decode_crop_flip(src: torch.Tensor, crop: Optional[Tuple[int, int, int, int]] = None, hflip: bool = False,
                      vflip: bool = False, velocity: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:

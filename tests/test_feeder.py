@@ -74,3 +74,25 @@ def test_decode_rejects_windows_outside_the_image():
     src = torch.zeros(3, 10, 12, dtype=torch.float16, device="cuda")
     with pytest.raises(RuntimeError):
         decode_crop_flip(src, (5, 0, 14, 8))
+
+
+def test_gbuffer_schema_and_motion_vector_decode():
+    """Offline side of the on-disk format (tools/ue_data.json:14-29, tools/data_preprocess.py:50-81).  The reference's
+    own functions read EXR files through cv2, which is not available here, so these two are checked against the
+    formulas as written there (parity unpinned)."""
+    from superresolution_amd.feeder import GBUFFER_SCHEMA, decode_motion_vector, merge_gbuffers
+    assert list(GBUFFER_SCHEMA) == ["WorldNormal", "Metallic", "Specular", "Roughness", "BaseColor", "SceneDepth"]
+    assert [hi - lo for lo, hi in GBUFFER_SCHEMA.values()] == [3, 1, 1, 1, 3, 1] and GBUFFER_SCHEMA["SceneDepth"] == (9, 10)
+    rng = np.random.default_rng(3)
+    planes = {k: rng.random((3, 4, 6), dtype=np.float32) for k in GBUFFER_SCHEMA}
+    merged = merge_gbuffers(planes)
+    assert merged.shape == (10, 4, 6)
+    assert np.array_equal(merged[6:9], planes["BaseColor"]) and np.array_equal(merged[9], planes["SceneDepth"][0])
+    assert np.array_equal(merged[3], planes["Metallic"][0])
+    with pytest.raises(KeyError):
+        merge_gbuffers({k: v for k, v in planes.items() if k != "Roughness"})
+    rgb = rng.random((3, 4, 6), dtype=np.float32)
+    mv = decode_motion_vector(rgb)
+    assert mv.shape == (2, 4, 6) and mv.dtype == np.float32
+    assert np.allclose(mv[0], -(rgb[0] - 0.5) * 3.0) and np.allclose(mv[1], (rgb[1] - 0.5) * 2.0)
+    assert np.array_equal(decode_motion_vector(np.full((3, 2, 2), 0.5, np.float32)), np.zeros((2, 2, 2), np.float32))
