@@ -326,54 +326,81 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
 
 // Sums the partial tiles in a fixed order and scatters them into the fp32 OIHW gradient.
 // Accumulator register r of lane l holds row (r&3) + 8(r>>2) + 4(l>>5) (= co) and column l&31 (= ci).
-// A block of 256 threads owns 32 consecutive outputs (one 128-byte line of every partial tile);
-// 8 thread groups each sum every 8th partial, then the 8 sums are added in a fixed order.
+// A block of 256 threads = 8 thread groups x 32 lanes; every group sums every 8th partial, then the 8 sums are added
+// in a fixed order.  Blocks below nvec_blocks reduce weight elements, four consecutive input channels per lane (one
+// 16-byte load per partial; 512 contiguous bytes per group); the blocks behind them reduce the bias gradient, one
+// element per lane.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cit_n, int nt,
                                                            float* __restrict__ dw, int w_i, int ci_off, int ci_real,
                                                            int co_real, int ci_pad32, float* __restrict__ db,
-                                                           int accumulate, float scale)
+                                                           int accumulate, float scale, int nvec_blocks)
 {
-    __shared__ float red[8][32];
+    __shared__ float4 red[8][32];
     const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + o;
     const int nw = co_real * 9 * ci_pad32;
-    // decode the output this thread column reduces: weight element, bias element, or nothing
-    int tile = 0, elem = -1;   // elem: float offset inside a wave's partial block
-    float* dst = nullptr;
-    if (idx < nw) {
-        const int ci = idx % ci_pad32;
-        const int tap = (idx / ci_pad32) % 9;
-        const int co = idx / (ci_pad32 * 9);
-        if (ci < ci_real) {
-            const int m = co & 31;
-            tile = (co >> 5) * cit_n + (ci >> 5);
-            elem = tap * 1024 + ((m & 3) + 4 * (m >> 3)) * 64 + (ci & 31) + 32 * ((m >> 2) & 1);
-            dst = dw + ((size_t)co * w_i + ci_off + ci) * 9 + tap;
+    const int ks = 4 / nt;
+    const int total = nwg * ks;
+    if ((int)blockIdx.x < nvec_blocks) {
+        const int idx = ((int)blockIdx.x * 32 + o) * 4;
+        int tile = 0, elem = -1, ci = 0, co = 0, tap = 0;
+        if (idx < nw) {
+            ci = idx % ci_pad32;
+            tap = (idx / ci_pad32) % 9;
+            co = idx / (ci_pad32 * 9);
+            if (ci < ci_real) {
+                const int m = co & 31;
+                tile = (co >> 5) * cit_n + (ci >> 5);
+                elem = tap * 1024 + ((m & 3) + 4 * (m >> 3)) * 64 + (ci & 31) + 32 * ((m >> 2) & 1);
+            }
         }
-    } else if (db != nullptr && idx < nw + co_real) {
-        const int co = idx - nw;
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (elem >= 0) {
+#pragma unroll 8
+            for (int k = part; k < total; k += 8) {   // unrolled: eight loads in flight, added in the same order
+                const int wg = k / ks, wv = tile + (k % ks) * nt;
+                const float4 v = *(const float4*)(partial + (size_t)(wg * 4 + wv) * 10240 + elem);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        red[part][o] = s;
+        __syncthreads();
+        if (part == 0 && elem >= 0) {
+            float4 t = red[0][o];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { const float4 r = red[k][o]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+            const float tv[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ci + j < ci_real) {
+                    float* dst = dw + ((size_t)co * w_i + ci_off + ci + j) * 9 + tap;
+                    *dst = accumulate ? *dst + tv[j] : tv[j];
+                }
+        }
+        return;
+    }
+    // bias gradient: the dz x ones accumulator of every (co tile, first ci tile) wave
+    const int co = ((int)blockIdx.x - nvec_blocks) * 32 + o;
+    int tile = 0, elem = -1;
+    if (db != nullptr && co < co_real) {
         const int m = co & 31;
         tile = (co >> 5) * cit_n;
         elem = 9 * 1024 + ((m & 3) + 4 * (m >> 3)) * 64 + 32 * ((m >> 2) & 1);
-        dst = db + co;
     }
-    const int ks = 4 / nt;
-    const int total = nwg * ks;
-    float s = 0.0f;
+    float sb = 0.0f;
     if (elem >= 0) {
         for (int k = part; k < total; k += 8) {
             const int wg = k / ks, wv = tile + (k % ks) * nt;
-            s += partial[(size_t)(wg * 4 + wv) * 10240 + elem];
+            sb += partial[(size_t)(wg * 4 + wv) * 10240 + elem];
         }
     }
-    red[part][o] = s;
+    red[part][o].x = sb;
     __syncthreads();
     if (part == 0 && elem >= 0) {
-        float t = red[0][o];
+        float t = red[0][o].x;
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][o];
+        for (int k = 1; k < 8; ++k) t += red[k][o].x;
         t *= scale;
-        *dst = accumulate ? *dst + t : t;
+        db[co] = accumulate ? db[co] + t : t;
     }
 }
 
@@ -417,9 +444,10 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
     int rc = srhip_check_launch("conv3x3_wgrad_kernel");
     if (rc != SRHIP_OK) return rc;
     const int ci_pad32 = (ci_real + 31) / 32 * 32;
-    const int nthreads = co_real * 9 * ci_pad32 + co_real;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(srhip_div_up(nthreads, 32)), dim3(256), 0, stream, p.partial, grid,
-                       C::CIT, C::NT, dw, w_i, ci_off, ci_real, co_real, ci_pad32, db, accumulate, scale);
+    const int nvec_blocks = srhip_div_up(co_real * 9 * ci_pad32, 128);
+    const int nbias_blocks = db != nullptr ? srhip_div_up(co_real, 32) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nvec_blocks + nbias_blocks), dim3(256), 0, stream, p.partial, grid,
+                       C::CIT, C::NT, dw, w_i, ci_off, ci_real, co_real, ci_pad32, db, accumulate, scale, nvec_blocks);
     return srhip_check_launch("wgrad_reduce_kernel");
 }
 
