@@ -153,3 +153,31 @@ def test_reprfn_training_step_reduces_loss_and_matches_infer():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
+
+
+def test_gradient_bucket_gather_mode_equals_in_place_mode():
+    """FlatGradAllReducer(gather=True) (backward assigns, one multi-tensor copy into the bucket) fills the bucket with
+    exactly what the in-place mode accumulates, and the fused optimiser then moves both replicas identically."""
+    from superresolution_amd import RepRFN
+    from superresolution_amd.dp import FlatGradAllReducer
+    torch.manual_seed(11)
+    a = RepRFN(3, 3, 48, 4, deploy=False).cuda().train()
+    b = RepRFN(3, 3, 48, 4, deploy=False).cuda().train()
+    b.load_state_dict(a.state_dict())
+    pa = [p for p in a.parameters() if p.requires_grad]
+    pb = [p for p in b.parameters() if p.requires_grad]
+    ra, rb = FlatGradAllReducer(pa), FlatGradAllReducer(pb, gather=True)
+    oa = torch.optim.AdamW(pa, lr=1e-4, weight_decay=1e-4, fused=True)
+    ob = torch.optim.AdamW(pb, lr=1e-4, weight_decay=1e-4, fused=True)
+    g = torch.Generator().manual_seed(12)
+    x, t = torch.rand(2, 3, 24, 32, generator=g).cuda(), torch.rand(2, 3, 96, 128, generator=g).cuda()
+    for _ in range(2):
+        for m, r, o in ((a, ra, oa), (b, rb, ob)):
+            r.zero_grad()
+            (m(x) - t).abs().mean().backward()
+            r.all_reduce()
+            r.check_views()
+        assert torch.equal(ra.flat, rb.flat)
+        oa.step(); ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p, q)
