@@ -38,6 +38,12 @@ def suite(verbose=True):
     # prev SR output warped by HR motion vectors (config C4): 3 channels fp32 NCHW + 2-channel motion
     fr, mv = f32(1, 3, H, W), (torch.randn(1, 2, H, W, device=dev) * 4).clamp(-32, 32)
     line("warp bilinear f32 NCHW 3ch @4K", timeit(lambda: F_.backward_warp(fr, mv, "bilinear", True)), (2 * 3 + 2) * H * W * 4)
+    # the same launch with spatially smooth motion (a rendered frame's vectors vary slowly; independent per-pixel vectors
+    # send every lane of a wave to a different cache line)
+    smooth = torch.nn.functional.interpolate(torch.randn(1, 2, 28, 48, device=dev) * 4, size=(H, W), mode="bilinear",
+                                             align_corners=True).clamp(-32, 32).contiguous()
+    line("warp bilinear f32 NCHW 3ch @4K, smooth motion", timeit(lambda: F_.backward_warp(fr, smooth, "bilinear", True)),
+         (2 * 3 + 2) * H * W * 4)
     fr16 = bf(1, H, W, 16)
     line("warp bilinear bf16 NHWC 16ch @4K", timeit(lambda: F_.backward_warp_nhwc(fr16, mv, "bilinear", True)), 2 * 16 * H * W * 2 + 2 * H * W * 4)
     # reference-shaped LR warp: 13 channels (frames + buffers) at 540x960
