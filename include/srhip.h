@@ -63,12 +63,13 @@ SRHIP_API int srhip_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, in
  * core/arch/RepRFN.py:158-161,252,315,322 (deploy form).
  *
  *   dst = alpha * act(conv(concat(src_a, src_b)) + bias) + res          (res_mode ADD)
- *   dst = res > 0 ? alpha * act(conv(...) + bias) : 0                   (res_mode MASK)
+ *   dst = X * (res > 0 ? 1 : m),  X = alpha * act(conv(...) + bias)     (res_mode MASK; m = 0, or with act NONE
+ *                                                                        m = the args' slope: LeakyReLU backward)
  *   dst = act(alpha * (conv(...) + bias) + res)                         (res_mode PRE)
  *
  * The MASK form is the backward of conv -> ReLU chains: with transpose_flip
  * weights the convolution yields dL/dx of the NEXT layer and `res` is the saved
- * ReLU output of THIS layer, so the product is dL/d(pre-activation) in one pass.
+ * (Leaky)ReLU output of THIS layer, so the product is dL/d(pre-activation) in one pass.
  *
  * The channel concat of core/models/model.py:169-170 is folded into the K loop:
  * src_b may be NULL (cb = 0).
@@ -85,7 +86,7 @@ typedef struct {
     int cout;            /* real output channels (<= 64) */
     int cout_stride;     /* channels of dst/res in NHWC form (multiple of 8, >= cout) */
     int act;             /* srhip_act */
-    float slope;         /* LeakyReLU negative slope */
+    float slope;         /* LeakyReLU negative slope; with act NONE and res_mode MASK: the mask's negative-side factor */
     float alpha;         /* scale applied after the activation (1.0 for none) */
     int dst_nchw_f32;    /* 1: write fp32 NCHW (network output / fp32-accumulate checks); no residual */
     int res_mode;        /* srhip_res_mode: how `res` enters the epilogue */

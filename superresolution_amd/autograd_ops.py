@@ -48,6 +48,52 @@ def conv3x3(x: Tensor, weight: Tensor, bias: Tensor, act: int = F_.ACT_NONE, slo
     return _Conv3x3.apply(x, weight, bias, act, slope, cout_stride)
 
 
+class _ConvLReluChain(Function):
+    """y_i = lrelu(conv3x3(y_{i-1}, W_i) + b_i), i = 1..n, as ONE autograd node (inputs: x, W_1, b_1, ..., W_n, b_n).
+    The intermediate maps have no other consumer, so the backward fuses each intermediate LeakyReLU backward into the
+    data-gradient launch of the layer behind it (MASK epilogue with the slope): one mask pass for the chain's output
+    instead of one per layer."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, slope: float, cout_stride: Optional[int], *wb: Tensor):
+        ws = [w.detach().float().contiguous() for w in wb[0::2]]
+        ys = [x]
+        for w, b in zip(ws, wb[1::2]):
+            cout, cin = w.shape[0], w.shape[1]
+            ys.append(F_.conv3x3(ys[-1], F_.conv3x3_pack_weights(w, cin, ys[-1].shape[-1]), b.detach().float().contiguous(), cout,
+                                 act=F_.ACT_LRELU, slope=slope, cout_stride=cout_stride))
+        ctx.save_for_backward(*ys, *ws)
+        ctx.n, ctx.slope = len(ws), slope
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        n = ctx.n
+        ys, ws = ctx.saved_tensors[:n + 1], ctx.saved_tensors[n + 1:]
+        grads = [None] * (2 * n)
+        dz = F_.lrelu_mask(dy.contiguous(), ys[n], ctx.slope)            # d(pre-activation) of the last layer
+        dx = None
+        for i in range(n, 0, -1):
+            w, x = ws[i - 1], ys[i - 1]
+            cout, cin = w.shape[0], w.shape[1]
+            dw, db = torch.empty_like(w), torch.empty((cout,), dtype=torch.float32, device=w.device)
+            F_.conv3x3_wgrad(x, dz, dw, db, cin, cout)
+            grads[2 * (i - 1)], grads[2 * (i - 1) + 1] = dw, db
+            if i > 1 or ctx.needs_input_grad[0]:
+                wp = F_.conv3x3_pack_weights(w, cout, dz.shape[-1], cout=cin, transpose_flip=True)
+                if i > 1:   # x is the LeakyReLU output of layer i-1: its backward rides on this launch
+                    dz = F_.conv3x3(dz, wp, None, cin, cout_stride=x.shape[-1], res=x, res_mode=F_.RES_MASK, slope=ctx.slope)
+                else:
+                    dx = F_.conv3x3(dz, wp, None, cin, cout_stride=x.shape[-1])
+        return (dx, None, None) + tuple(grads)
+
+
+def conv3x3_lrelu_chain(x: Tensor, layers, slope: float, cout_stride: Optional[int] = None) -> Tensor:
+    """layers: [(weight, bias), ...] applied in order, each followed by LeakyReLU(slope)."""
+    flat = [t for wb in layers for t in wb]
+    return _ConvLReluChain.apply(x, slope, cout_stride, *flat)
+
+
 def conv1x1(x: Tensor, weight: Tensor, bias: Tensor, cout_stride: Optional[int] = None) -> Tensor:
     """1x1 convolution as the centre tap of a 3x3 kernel of zeros; autograd slices the centre tap of the 3x3
     weight gradient back out."""

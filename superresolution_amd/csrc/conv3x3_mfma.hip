@@ -42,6 +42,7 @@ struct ConvParams {
     int cout, cout_stride;
     int cout_w;     // channels this launch writes per pixel (<= cout_stride: a channel slice of a wider tensor)
     float slope, alpha;  // slope: 1 (no activation), 0 (ReLU) or the LeakyReLU slope
+    float mask_slope;    // MASK epilogue: factor where the mask tensor is <= 0 (0: ReLU backward, s: LeakyReLU backward)
     int nstrips, nsegs, seg_h, total_items;
 };
 
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             }
             if constexpr (C::RES_PRE) t += rv;
             float v = fmaxf(t, t * p.slope);  // act(t) = max(t, slope * t), slope in {1, 0, s}
-            if constexpr (C::RES_MASK) v = rv > 0.0f ? v : 0.0f;
+            if constexpr (C::RES_MASK) v = rv > 0.0f ? v : v * p.mask_slope;
             else if constexpr (C::HAS_RES && !C::RES_PRE) v += rv;
             ev[e] = v;
         };
@@ -805,6 +806,9 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     p.cout = a->cout; p.cout_stride = a->cout_stride; p.cout_w = cout_w;
     p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
     p.alpha = a->alpha;
+    // MASK form without an activation: the args' slope is the negative-side factor of the mask (LeakyReLU backward)
+    p.mask_slope = (a->res_mode == SRHIP_RES_MASK && a->act == SRHIP_ACT_NONE) ? a->slope : 0.0f;
+    SRHIP_REQUIRE(p.mask_slope >= 0.0f && p.mask_slope <= 1.0f, "conv3x3: the mask's slope must lie in [0, 1] (got %g)", (double)p.mask_slope);
     const int kc = (a->ca + a->cb) / 16;
     const int ct = (a->cout + 31) / 32;
     // supported source splits: one tensor of 16/32/48/64 channels, or concat(32 channels, 64 channels)

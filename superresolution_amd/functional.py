@@ -81,7 +81,7 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
             cout_stride: Optional[int] = None, out: Optional[torch.Tensor] = None,
             res_mode: int = RES_ADD, ca_slice: Optional[tuple] = None, out_off: Optional[int] = None) -> torch.Tensor:
     """dst = alpha * act(conv3x3(concat(src_a, src_b)) + bias) + res   (NHWC bf16 activations);
-    with ``res_mode=RES_MASK``: dst = res > 0 ? alpha * act(...) : 0;
+    with ``res_mode=RES_MASK``: dst = alpha * act(...) * (res > 0 ? 1 : m), m = 0 or (act NONE) m = ``slope``;
     with ``res_mode=RES_PRE``: dst = act(alpha * (conv + bias) + res) (partial sums of layers wider than one launch).
 
     ``ca_slice=(off, n)``: read only channels [off, off+n) of src_a (n a multiple of 16, off of 8) - no copy.

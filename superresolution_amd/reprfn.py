@@ -299,11 +299,9 @@ class RepRFN(nn.Module):
                                          for bi in range(1, 5) for ri in range(1, 4))
         for bi in range(1, 5):
             rfb = getattr(self, f"reprfb{bi}")
-            t = out
-            for ri in range(1, 4):
-                k, b = merged[(bi - 1) * 3 + ri - 1]
-                t = A.conv3x3(t, k, b, act=F_.ACT_LRELU, slope=_SLOPE, cout_stride=cs)
-            t = A.add(A.conv3x3(t, rfb.conv3.weight, rfb.conv3.bias, act=F_.ACT_LRELU, slope=_SLOPE, cout_stride=cs), out)
+            # repblock1..3 and conv3, each with LeakyReLU, as one chain (RepRFN.py:257-262)
+            layers = merged[(bi - 1) * 3:bi * 3] + [(rfb.conv3.weight, rfb.conv3.bias)]
+            t = A.add(A.conv3x3_lrelu_chain(out, layers, _SLOPE, cout_stride=cs), out)
             out = _esa_train(rfb.esa, t)
         out = A.add(A.conv3x3(out, self.lr_conv.weight, self.lr_conv.bias, cout_stride=cs), fea)
         up = self.upsampler

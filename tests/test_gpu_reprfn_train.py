@@ -181,3 +181,57 @@ def test_gradient_bucket_gather_mode_equals_in_place_mode():
         oa.step(); ob.step()
     for p, q in zip(pa, pb):
         assert torch.equal(p, q)
+
+
+def test_mask_epilogue_with_slope_and_the_layer_chain():
+    """MASK epilogue with a negative-side slope = LeakyReLU backward fused into a data-gradient launch: against the
+    unfused pair (convolution, then lrelu_mask) it differs only by the second bf16 rounding; the chained Function built
+    on it gives the gradients of the per-layer Functions."""
+    from superresolution_amd import autograd_ops as A
+    from superresolution_amd import functional as F_
+    g = torch.Generator().manual_seed(21)
+    n, h, w, c = 2, 19, 23, 64
+    dz = _nhwc(_bf(torch.randn(n, c, h, w, generator=g)))
+    y = _nhwc(_bf(torch.randn(n, c, h, w, generator=g)))
+    wt = (torch.randn(c, c, 3, 3, generator=g) * 0.05).cuda()
+    wp = F_.conv3x3_pack_weights(wt, c, c)
+    fused = F_.conv3x3(dz, wp, None, c, res=y, res_mode=F_.RES_MASK, slope=0.05)
+    plain = F_.conv3x3(dz, wp, None, c)
+    two = F_.lrelu_mask(plain, y, 0.05)
+    assert (fused.float() - two.float()).abs().max().item() <= 2e-3 * max(1.0, plain.float().abs().max().item())
+    pos = (y > 0)
+    assert torch.equal(fused[pos], plain[pos])                       # the positive side passes unchanged
+    relu = F_.conv3x3(dz, wp, None, c, res=y, res_mode=F_.RES_MASK)   # slope 0: ReLU backward as before
+    assert torch.equal(relu[pos], plain[pos]) and float(relu[~pos].abs().max()) == 0.0
+
+    torch.manual_seed(22)
+    ws = [torch.nn.Parameter((torch.randn(48, 48, 3, 3) * 0.05).cuda()) for _ in range(3)]
+    bs = [torch.nn.Parameter((torch.randn(48) * 0.1).cuda()) for _ in range(3)]
+    x0 = torch.zeros(1, 21, 17, 64).cuda()
+    x0[..., :48] = torch.randn(1, 21, 17, 48, generator=g).cuda()
+    x0 = x0.to(torch.bfloat16)
+    cot = torch.zeros(1, 21, 17, 64).cuda()
+    cot[..., :48] = torch.randn(1, 21, 17, 48, generator=g).cuda()
+    cot = cot.to(torch.bfloat16)
+
+    def run(chain):
+        for p in ws + bs:
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        if chain:
+            out = A.conv3x3_lrelu_chain(x, list(zip(ws, bs)), 0.05, cout_stride=64)
+        else:
+            out = x
+            for wgt, b in zip(ws, bs):
+                out = A.conv3x3(out, wgt, b, act=F_.ACT_LRELU, slope=0.05, cout_stride=64)
+        out.backward(cot)
+        return out.detach(), x.grad, [p.grad.clone() for p in ws + bs]
+
+    o1, dx1, g1 = run(False)
+    o2, dx2, g2 = run(True)
+    assert torch.equal(o1, o2)
+    rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+    assert rel(dx2, dx1) <= 1e-2
+    for a, b in zip(g2, g1):
+        assert rel(a, b) <= 1e-2
+    assert float(dx2[..., 48:].abs().max()) == 0.0                    # channel padding stays zero
