@@ -232,6 +232,10 @@ SRHIP_API int srhip_backward_warp_bwd_f32(const float* frame, const float* motio
  *   unshuffle: src (N,C,H*r,W*r) -> dst (N,C*r*r,H,W)          */
 SRHIP_API int srhip_pixel_shuffle(const void* src, void* dst, int n, int c, int h, int w, int r,
                                   int elem_size, void* stream);
+/* nn.PixelUnshuffle(4) (core/models/model_final.py:234,408) fused with the layout conversion in front of the
+ * convolutions that consume it: src (N,c,4h,4w) fp32 NCHW -> dst (N,h,w,16c) bf16 NHWC, channel c*16 + i*4 + j.
+ * Equal bit for bit to srhip_pixel_unshuffle followed by srhip_nchw_f32_to_nhwc_bf16.  c <= 23. */
+SRHIP_API int srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, void* stream);
 SRHIP_API int srhip_pixel_unshuffle(const void* src, void* dst, int n, int c, int h, int w, int r,
                                     int elem_size, void* stream);
 /* Fused network head: NHWC bf16 (N,H,W,cstride>=c*r*r) -> NCHW fp32 (N,c,H*r,W*r). */

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "srhip_backward_warp_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_backward_warp_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "srhip_pixel_shuffle": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "srhip_pixel_unshuffle": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_pixel_shuffle_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_nearest_down": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_double, c_int, c_void_p]),

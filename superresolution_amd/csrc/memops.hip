@@ -142,6 +142,45 @@ __global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_tiled_kernel(const 
     }
 }
 
+// nn.PixelUnshuffle(4) of an fp32 NCHW tensor written straight as NHWC bf16 (core/models/model_final.py:234,408 feed
+// convolutions): out[n][y][x][c*16 + i*4 + j] = in[n][c][4y+i][4x+j].  A block takes 64 output pixels; every lane reads
+// 16 contiguous bytes (the four j of one (c, i)), pixel index fastest, and the 64 * 16c * 2 output bytes leave in linear
+// order through LDS.  LDS rows are 8-byte entries of four channels, padded by two entries.
+__global__ __launch_bounds__(256) void pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ src,
+                                                                                    unsigned short* __restrict__ dst, int n, int c,
+                                                                                    int h, int w)
+{
+    extern __shared__ uint4 tile[];
+    uint2* t2 = (uint2*)tile;
+    const int nq = c * 4, q = nq + 2, cg = c * 2;          // (c, i) pairs per pixel; row stride; 16-byte groups per pixel
+    const long long total = (long long)n * h * w;
+    const long long ntiles = (total + kLayoutTile - 1) / kLayoutTile;
+    const long long H = 4ll * h, W = 4ll * w;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long p0 = t * kLayoutTile;
+        const int npx = (int)(total - p0 < kLayoutTile ? total - p0 : kLayoutTile);
+        for (int it = threadIdx.x; it < kLayoutTile * nq; it += blockDim.x) {
+            const int px = it & (kLayoutTile - 1), ci = it / kLayoutTile;
+            if (px < npx) {
+                const long long p = p0 + px;
+                const int x = (int)(p % w);
+                const long long r = p / w;
+                const int y = (int)(r % h);
+                const long long img = r / h;
+                const float4 v = *(const float4*)(src + ((img * c + (ci >> 2)) * H + 4ll * y + (ci & 3)) * W + 4ll * x);
+                t2[px * q + ci] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            }
+        }
+        __syncthreads();
+        uint4* out = (uint4*)(dst + p0 * (16ll * c));
+        for (int it = threadIdx.x; it < npx * cg; it += blockDim.x) {
+            const int px = it / cg, g = it - px * cg;
+            out[it] = *(const uint4*)(t2 + px * q + 2 * g);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst,
                                              int n, int c, long long hw, int cstride)
 {
@@ -1258,6 +1297,20 @@ SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, in
             break;
     }
     return srhip_check_launch("nchw_f32_to_nhwc_bf16");
+}
+
+SRHIP_API int srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16: bad shape");
+    SRHIP_REQUIRE((size_t)src % 16 == 0 && (size_t)dst % 16 == 0, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16: 16-byte aligned tensors");
+    const size_t lds = (size_t)kLayoutTile * (c * 4 + 2) * sizeof(uint2);
+    SRHIP_REQUIRE(lds <= 48 * 1024, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16: at most 23 input channels (got %d)", c);
+    const long long ntiles = ((long long)n * h * w + kLayoutTile - 1) / kLayoutTile;
+    const long long cap = (long long)srhip_num_cus() * 16;
+    hipLaunchKernelGGL(pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds,
+                       (hipStream_t)stream, src, (unsigned short*)dst, n, c, h, w);
+    return srhip_check_launch("pixel_unshuffle4_nchw_f32_to_nhwc_bf16");
 }
 
 SRHIP_API int srhip_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, int cstride,

@@ -510,6 +510,19 @@ def pixel_unshuffle(x: torch.Tensor, r: int) -> torch.Tensor:
     return out
 
 
+def pixel_unshuffle_to_nhwc_bf16(x: torch.Tensor, r: int) -> torch.Tensor:
+    """nchw_f32_to_nhwc_bf16(pixel_unshuffle(x, r)) -- one kernel for r = 4 and up to 23 channels, the pair otherwise."""
+    x = _req(x, torch.float32, "x")
+    n, c, hr, wr = x.shape
+    if hr % r or wr % r:
+        raise ValueError("pixel_unshuffle: spatial size not divisible by r")
+    if r != 4 or c > 23:
+        return nchw_f32_to_nhwc_bf16(pixel_unshuffle(x, r))
+    out = torch.empty((n, hr // 4, wr // 4, 16 * c), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(x.data_ptr(), out.data_ptr(), n, c, hr // 4, wr // 4, _stream()))
+    return out
+
+
 def pixel_shuffle_nhwc_to_nchw_f32(x: torch.Tensor, c: int, r: int) -> torch.Tensor:
     x = _req(x, torch.bfloat16, "x")
     n, h, w, cs = x.shape

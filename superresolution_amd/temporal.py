@@ -98,9 +98,9 @@ class GBuffersEncoder(nn.Module):
     def run(self, buffer: Tensor) -> Tensor:
         """buffer (B,10,H,W) fp32 -> (B,h,w,cout) bf16 (model_final.py:250-258)."""
         r2 = self.factor ** 2
-        folded = F_.pixel_unshuffle(buffer, self.factor)               # channel c*r2 + i*r + j
-        # normal (0:3), base colour (6:9) and depth (9:10) planes, folded
-        fn = F_.nchw_f32_to_nhwc_bf16(folded)
+        # folded buffer, channel c*r2 + i*r + j, straight in the convolutions' layout; below: normal (0:3), base colour
+        # (6:9) and depth (9:10) planes of it
+        fn = F_.pixel_unshuffle_to_nhwc_bf16(buffer, self.factor)
         fmap = _run_seq(self.conv_main, fn)
         # picked from the converted map (the conversion rounds element by element, so the order does not matter)
         if r2 % 2 == 0 and fn.shape[-1] % 2 == 0:      # copy channel pairs as 32-bit words
@@ -223,8 +223,7 @@ class MainNetwork(nn.Module):
         for i in range(nb):
             F_.gradient_map(hr_buffer[i:i + 1, 0:3], self.grad_map[0].eps, out=gfull[i:i + 1, 0:3])
             F_.gradient_map(hr_buffer[i:i + 1, 6:9], self.grad_map[0].eps, out=gfull[i:i + 1, 3:6])
-        gmap = F_.pixel_unshuffle(gfull, self.sr_scale)
-        grad, g_self, g_cross = self.attn_grad.run(F_.nchw_f32_to_nhwc_bf16(gmap))
+        grad, g_self, g_cross = self.attn_grad.run(F_.pixel_unshuffle_to_nhwc_bf16(gfull, self.sr_scale))
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
         # model_final.py:422 (element-wise, channel-broadcast gates), one kernel
         cur = F_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)

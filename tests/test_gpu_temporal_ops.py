@@ -175,3 +175,16 @@ def test_dilate_velocity_bit_exact(F_):
         assert np.array_equal(F_.dilate_velocity(dev(m), dev(d), k).cpu().numpy(), orc.dilate_velocity(m, d, k))
     with pytest.raises(ValueError):
         F_.dilate_velocity(dev(m), dev(d[:, :, :0]), 3)
+
+
+@pytest.mark.parametrize("shape", [(1, 10, 16, 24), (2, 6, 20, 52), (3, 1, 4, 4), (1, 23, 8, 12)])
+def test_fused_pixel_unshuffle_layout_bit_exact(F_, shape):
+    """PixelUnshuffle(4) + NHWC bf16 conversion in one kernel == the two kernels in sequence (partial 64-pixel tiles,
+    tiles that straddle rows and images); other factors and wider inputs take the pair."""
+    rng = np.random.default_rng(sum(shape))
+    x = dev(rng.standard_normal(shape).astype(np.float32))
+    got = F_.pixel_unshuffle_to_nhwc_bf16(x, 4)
+    ref = F_.nchw_f32_to_nhwc_bf16(F_.pixel_unshuffle(x, 4))
+    assert got.shape == ref.shape and got.dtype == torch.bfloat16 and torch.equal(got, ref)
+    x2 = dev(rng.standard_normal((1, 3, 6, 10)).astype(np.float32))
+    assert torch.equal(F_.pixel_unshuffle_to_nhwc_bf16(x2, 2), F_.nchw_f32_to_nhwc_bf16(F_.pixel_unshuffle(x2, 2)))
