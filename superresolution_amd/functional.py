@@ -277,7 +277,7 @@ def _k_slices(cpad: int):
     return out
 
 
-def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 1,
+def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 1,
                 act: int = ACT_NONE, slope: float = 0.0, res: Optional[torch.Tensor] = None,
                 alpha: float = 1.0) -> torch.Tensor:
     """alpha * act(nn.Conv2d(x)) + res on an NHWC bf16 tensor with any channel count, on the MFMA kernel
@@ -294,16 +294,32 @@ def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     x carries pad16(cin) channels; the result carries pad16(cout).  `weight` / `bias` may be Parameters: their
     packed forms are cached per tensor object."""
     cout, cin, kh, kw = weight.shape
-    cpad = x.shape[-1]
+    # x may be a tuple of maps: the layer then reads their channel concatenation (torch.concat(..., dim=1) in front of a
+    # convolution, core/models/model_final.py:298,375-379,424) without materialising it -- every K-slice is read from
+    # the map that holds it
+    srcs = list(x) if isinstance(x, (tuple, list)) else [x]
+    if len(srcs) > 1:
+        if any(t.shape[:3] != srcs[0].shape[:3] for t in srcs) or sum(t.shape[-1] for t in srcs) - cin >= 16:
+            raise ValueError("conv2d_auto: concatenated sources must share (N,H,W) and carry no channel padding except the last")
+    cpad = sum(t.shape[-1] for t in srcs)
     as3x3 = (kh, kw, padding) == (3, 3, 1) and stride in (1, 2)
     as1x1 = (kh, kw, padding, stride) == (1, 1, 0, 1)
     if not (as3x3 or as1x1) or (alpha != 1.0 and (cpad > 64 or cout > 64 or stride != 1)):
-        return conv2d_direct(x, weight.detach(), None if bias is None else bias.detach(), cin, stride=stride,
+        xin = srcs[0]
+        for t in srcs[1:]:
+            xin = concat_nhwc(xin, t)
+        return conv2d_direct(xin, weight.detach(), None if bias is None else bias.detach(), cin, stride=stride,
                              padding=padding, res=res, act=act, slope=slope, alpha=alpha)
     wd = weight.detach()
     bd = None if bias is None else bias.detach()
-    slices = [(k0, k1) for (k0, k1) in _k_slices(cpad) if min(k1, cin) > k0]   # drop slices that hold only channel padding
-    n_, h_, w_ = x.shape[:3]
+    # (source, first channel inside it, weight channel range); slices that hold only channel padding are dropped
+    slices, wk = [], 0
+    for t in srcs:
+        for (a, b) in _k_slices(t.shape[-1]):
+            if min(wk + b, cin) > wk + a:
+                slices.append((t, a, wk + a, wk + b))
+        wk += t.shape[-1]
+    n_, h_, w_ = srcs[0].shape[:3]
 
     def packed(k0, k1, off, n):
         def build():
@@ -318,20 +334,19 @@ def conv2d_auto(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     # every launch reads its 64-channel input slice in place and writes (accumulates) its 64-channel output slice in
     # place: no slice copies, no concat
     fuse_res = res is not None and stride == 1 and len(slices) == 1 and cout <= 64
-    out = torch.empty((n_, h_, w_, pad16(cout)), dtype=torch.bfloat16, device=x.device)
-    whole_in = len(slices) == 1 and slices[0] == (0, cpad)
+    out = torch.empty((n_, h_, w_, pad16(cout)), dtype=torch.bfloat16, device=srcs[0].device)
     for off in range(0, cout, 64):
         n = min(64, cout - off)
         b = None if bd is None else bd[off:off + n].contiguous()
-        for i, (k0, k1) in enumerate(slices):
+        for i, (src, a, k0, k1) in enumerate(slices):
             last = i == len(slices) - 1
             wp = packed(k0, k1, off, n)
-            sl = None if whole_in else (k0, k1 - k0)
+            sl = None if (a == 0 and k1 - k0 == src.shape[-1]) else (a, k1 - k0)
             if i == 0:
-                conv3x3(x, wp, b, n, res=res if (fuse_res and last) else None, act=act if last else ACT_NONE, slope=slope,
+                conv3x3(src, wp, b, n, res=res if (fuse_res and last) else None, act=act if last else ACT_NONE, slope=slope,
                         alpha=alpha, ca_slice=sl, out=out, out_off=off)
             else:
-                conv3x3(x, wp, None, n, res=out, res_mode=RES_PRE, act=act if last else ACT_NONE, slope=slope, ca_slice=sl,
+                conv3x3(src, wp, None, n, res=out, res_mode=RES_PRE, act=act if last else ACT_NONE, slope=slope, ca_slice=sl,
                         out=out, out_off=off)
     if stride == 2:
         out = max_pool2d_nhwc(out, 1, 2)  # out[i, j] = stride-1 result at (2i, 2j)

@@ -151,7 +151,7 @@ class HistoryRefiner(nn.Module):
         """x (N,h,w,64) bf16; aux (N,14,h,w), motion (N,2,h,w) fp32 (model_final.py:295-315)."""
         x_in = self.refine_in.run(x)
         extra = F_.nchw_f32_to_nhwc_bf16(torch.cat((aux, motion.abs()), dim=1).contiguous())   # 16 channels
-        x0 = self.conv0.run(F_.concat_nhwc(x_in, extra))
+        x0 = self.conv0.run((x_in, extra))                # the layer reads the concatenation in place
         x1 = self.conv1.run(self.down0.run(x0))
         x2 = self.conv2.run(self.down1.run(x1))
         x3 = self.conv3.run(self.down2.run(x2))
@@ -188,9 +188,9 @@ class FusionNetwork(nn.Module):
         f2 = _run_seq(self.conv2, self.down2.run(f1))
         f3 = _run_seq(self.conv3, self.down3.run(f2))
         f3 = _run_seq(self.up3, f3)
-        f2 = _run_seq(self.up2, F_.concat_nhwc(f3, f2))
-        f1 = _run_seq(self.up1, F_.concat_nhwc(f2, f1))
-        return _run_seq(self.up0, F_.concat_nhwc(f1, f0))
+        f2 = _run_seq(self.up2, (f3, f2))                 # skip connections: read in place, never concatenated
+        f1 = _run_seq(self.up1, (f2, f1))
+        return _run_seq(self.up0, (f1, f0))
 
 
 class Attention(nn.Module):
@@ -227,7 +227,7 @@ class MainNetwork(nn.Module):
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
         # model_final.py:422 (element-wise, channel-broadcast gates), one kernel
         cur = F_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)
-        return self.main_network.run(F_.concat_nhwc(F_.concat_nhwc(cur, fmap_history), fmap_gbuffer))
+        return self.main_network.run((cur, fmap_history, fmap_gbuffer))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -346,7 +346,7 @@ class SuperSampler(nn.Module):
 
         fmap = self.main_network.run(fmap_current, fmap_history, fmap_bf, hr_buffer)
         c0, c2 = self.conv_out[0], self.conv_out[2]
-        t = F_.conv2d_auto(F_.concat_nhwc(fmap, fmap_shadow), c0.weight, c0.bias)
+        t = F_.conv2d_auto((fmap, fmap_shadow), c0.weight, c0.bias)
         hr = F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale)
         wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)
         sr_frame = F_.conv3x3(F_.nchw_f32_to_nhwc_bf16(hr), wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)

@@ -99,3 +99,27 @@ def test_channel_slices_in_place_equal_copies_bit_for_bit():
         F_.conv3x3(x, wp, b, 48, ca_slice=(100, 64))
     with pytest.raises(ValueError):
         F_.conv3x3(x, wp, b, 48, out=wide, out_off=160)   # 160 + pad16(48) > 192
+
+
+@pytest.mark.parametrize("chs,cout,stride", [((64, 64), 64, 1), ((192, 192), 128, 1), ((64, 32, 64), 160, 1), ((64, 16), 64, 2), ((32, 16), 48, 1)])
+def test_concatenated_sources_are_read_in_place(chs, cout, stride):
+    """conv2d_auto on a tuple of maps == conv2d_auto on their channel concatenation (torch.concat in front of a
+    convolution, core/models/model_final.py:298,375-379,424): bit for bit when the sources fall on the same 64-channel
+    slices, within the bf16 partial-sum rounding otherwise."""
+    from superresolution_amd import functional as F_
+    g = torch.Generator(device="cuda").manual_seed(sum(chs) + cout)
+    n, h, w = 1, 22, 36
+    xs = [(torch.rand(n, h, w, c, device="cuda", generator=g) - 0.4).to(torch.bfloat16) for c in chs]
+    cin = sum(chs)
+    wt = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) * (1.0 / (3.0 * cin ** 0.5))
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    got = F_.conv2d_auto(tuple(xs), wt, b, stride=stride, padding=1, act=F_.ACT_RELU)
+    ref = F_.conv2d_auto(torch.cat(xs, dim=-1).contiguous(), wt, b, stride=stride, padding=1, act=F_.ACT_RELU)
+    assert got.shape == ref.shape
+    same_slices = all(c % 64 == 0 for c in chs[:-1])
+    if same_slices:
+        assert torch.equal(got, ref)
+    else:
+        assert (got.float() - ref.float()).abs().max().item() <= 2e-2
+    with pytest.raises(ValueError):
+        F_.conv2d_auto((xs[0], xs[0][:, :-1]), wt, b)
