@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training leg of the default workload")
     ap.add_argument("--train-batch", type=int, default=16, help="crops per GPU per step (train workload)")
     ap.add_argument("--train-crop", type=int, default=1024, help="HR crop size (train workload)")
-    ap.add_argument("--cpu-train-crop", type=int, default=512, help="HR crop size of the CPU-oracle training sample")
+    ap.add_argument("--cpu-train-crop", type=int, default=1024, help="HR crop size of the CPU training-step sample")
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[288, 384], help="LR crop (h w) of the CPU-oracle sample")
     return ap.parse_args()
 
@@ -139,50 +139,95 @@ def measured_traffic_bytes():
         return None
 
 
+def _cpu_threads():
+    cores = min(16, os.cpu_count() or 1)   # the GPU box grants 16 host cores per GPU
+    torch.set_num_threads(cores)
+    return cores
+
+
 def cpu_baseline(crop):
-    """Oracle (CPU port of the reference path) on a bounded crop, scaled to 4K frames/s."""
+    """The reference's CPU path beside the GPU: the default network composed from the stock torch operators the
+    reference itself calls (F.conv2d / F.grid_sample / torch.cat, fp32, ATen CPU kernels; oracle/torch_checkers.py,
+    pinned to the reference's own output by the CPU suite) on ONE full 270x480 -> 1080x1920 frame (BASELINE configs[0]),
+    median of 3, scaled by pixel count (x 1/4) to 4K frames/s.  The C restatement (oracle/oracle.c) is timed next to it
+    on a bounded crop."""
     import numpy as np
     from oracle import oracle as orc
+    from oracle.torch_checkers import supersampler_forward_torch
     from superresolution_amd import SuperSampler
-    cores = min(16, os.cpu_count() or 1)
-    orc.set_threads(cores)
+    cores = _cpu_threads()
     torch.manual_seed(42)
-    sd = {k: v.numpy() for k, v in SuperSampler(3, 10, 1).state_dict().items()}
+    sd_t = {k: v.detach().clone() for k, v in SuperSampler(3, 10, 1).state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    h1, w1 = LR_H // 2, LR_W // 2
+    lr = torch.rand(1, 3, h1, w1, generator=g)
+    hb = torch.rand(1, 10, h1 * SCALE, w1 * SCALE, generator=g)
+    ts = []
+    with torch.no_grad():
+        supersampler_forward_torch(sd_t, lr[..., :16, :16], hb[..., :64, :64])  # page in
+        for _ in range(3):
+            t0 = time.perf_counter()
+            supersampler_forward_torch(sd_t, lr, hb)
+            ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[1]
+    frac = (h1 * w1) / float(LR_H * LR_W)
+    res = {"value": frac / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"stock torch CPU operators (F.conv2d / F.grid_sample / torch.cat, fp32, {cores} threads) composing "
+                     f"core/models/model.py:147-175 on one full {h1}x{w1} -> {h1 * SCALE}x{w1 * SCALE} frame, median of 3 "
+                     f"({dt:.2f} s), scaled by pixel count to a 540x960 -> 2160x3840 frame"}
+    # the C restatement on its bounded crop
+    orc.set_threads(cores)
+    sd = {k: v.numpy() for k, v in sd_t.items()}
     ch, cw = crop
     rng = np.random.default_rng(42)
-    lr = rng.random((1, 1, 3, ch, cw), dtype=np.float32)
-    hb = rng.random((1, 1, 10, ch * SCALE, cw * SCALE), dtype=np.float32)
-    orc.supersampler_forward(sd, lr[:, :, :, :8, :8], hb[:, :, :, :32, :32])  # page in
+    lr_c = rng.random((1, 1, 3, ch, cw), dtype=np.float32)
+    hb_c = rng.random((1, 1, 10, ch * SCALE, cw * SCALE), dtype=np.float32)
+    orc.supersampler_forward(sd, lr_c[:, :, :, :8, :8], hb_c[:, :, :, :32, :32])  # page in
     t0 = time.perf_counter()
-    orc.supersampler_forward(sd, lr, hb)
-    dt = time.perf_counter() - t0
-    frac = (ch * cw) / float(LR_H * LR_W)
-    return {"value": frac / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle forward on one LR {ch}x{cw} -> HR {ch * SCALE}x{cw * SCALE} crop ({dt:.2f} s), "
-                      f"scaled by pixel count to a 540x960 -> 2160x3840 frame"}
+    orc.supersampler_forward(sd, lr_c, hb_c)
+    dto = time.perf_counter() - t0
+    res["oracle"] = {"value": (ch * cw) / float(LR_H * LR_W) / dto, "unit": "frames/s", "cores": cores, "kind": "port",
+                     "sample": f"oracle/oracle.c forward on one LR {ch}x{cw} -> HR {ch * SCALE}x{cw * SCALE} crop ({dto:.2f} s), "
+                               f"scaled by pixel count to a 540x960 -> 2160x3840 frame"}
+    return res
 
 
 def cpu_baseline_train(crop):
-    """Oracle forward + backward of the network (the loss gradient is a fixed tensor) on ONE HR crop,
-    scaled by pixel count to 1024x1024 crops/s."""
-    import numpy as np
-    from oracle import oracle as orc
+    """One whole training step (core/trainer.py:143-161: forward, clip, L1 + 0.5 SSIM, backward, AdamW) on ONE HR crop
+    (batch 1: a batch of 16 needs > 100 GB of fp32 activations) with stock torch operators and torch autograd on the
+    host cores, median of 3, scaled by pixel count to 1024x1024 crops/s."""
+    from oracle.torch_checkers import LossGroup, supersampler_forward_torch
     from superresolution_amd import SuperSampler
-    cores = min(16, os.cpu_count() or 1)
-    orc.set_threads(cores)
+    cores = _cpu_threads()
     torch.manual_seed(42)
-    sd = {k: v.numpy() for k, v in SuperSampler(3, 10, 1).state_dict().items()}
-    rng = np.random.default_rng(42)
-    lr = rng.random((1, 1, 3, crop // SCALE, crop // SCALE), dtype=np.float32)
-    hb = rng.random((1, 1, 10, crop, crop), dtype=np.float32)
-    dsr = (rng.random((1, 3, crop, crop), dtype=np.float32) - 0.5) / (3.0 * crop * crop)
-    orc.supersampler_forward_backward(sd, lr[..., :8, :8], hb[..., :32, :32], lambda sr: dsr[..., :32, :32])  # page in
-    t0 = time.perf_counter()
-    orc.supersampler_forward_backward(sd, lr, hb, lambda sr: dsr)
-    dt = time.perf_counter() - t0
+    model = SuperSampler(3, 10, 1)
+    sd = dict(model.named_parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    lg = LossGroup(1.0, 0.5, report=False)
+    g = torch.Generator().manual_seed(42)
+    alias = torch.rand(1, 3, crop, crop, generator=g)
+    target = torch.rand(1, 3, crop, crop, generator=g)
+    hb = torch.rand(1, 10, crop, crop, generator=g)
+
+    def step(n):
+        lr = torch.nn.functional.interpolate(alias[..., :n, :n], scale_factor=1.0 / SCALE, mode="nearest")
+        sr = torch.clip(supersampler_forward_torch(sd, lr, hb[..., :n, :n]), 0.0, 10.0)
+        opt.zero_grad()
+        loss, _ = lg({"hr_frames": target[..., :n, :n], "sr_frames": sr})
+        loss.backward()
+        opt.step()
+
+    step(64)  # page in
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step(crop)
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[1]
     return {"value": (crop * crop) / (1024.0 * 1024.0) / dt, "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"oracle forward + backward (loss and optimiser excluded) on one HR {crop}x{crop} crop ({dt:.2f} s), "
-                      f"scaled by pixel count to 1024x1024 crops"}
+            "sample": f"stock torch CPU operators + torch autograd (fp32, {cores} threads): nearest down-sampling + forward + clip + "
+                      f"L1 + 0.5*SSIM + backward + AdamW on one HR {crop}x{crop} crop, median of 3 ({dt:.2f} s), scaled by pixel "
+                      f"count to 1024x1024 crops"}
 
 
 def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=True):
@@ -195,7 +240,8 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
     B, S = args.train_batch, args.train_crop
     model = make_model(dev).train()
     broadcast_parameters(model, src=0)
-    red = FlatGradAllReducer(model.parameters())
+    # two buckets, each all-reduced asynchronously as soon as the backward pass has queued its last weight gradient
+    red = FlatGradAllReducer(model.parameters(), buckets=2).attach(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)  # configs/trainer/4x_H2.yaml:12-17
     loss_group = FusedLossGroup(1.0, 0.5, clip=(0.0, 10.0), report=False)  # clip: core/trainer.py:154-156
     g = torch.Generator().manual_seed(42 + rank)
@@ -441,14 +487,58 @@ def run_aux_infer(args, world, rank, dev, dist):
                          "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None}}
 
 
+def emit(args, res):
+    """Rank 0's ONE JSON line; carries the number of ranks that really ran and the collective backend."""
+    res.update(args.ranks_info)
+    print(json.dumps(res), flush=True)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks (one process per GPU) through
+    torch.distributed.run BEFORE this process touches a GPU, relay rank 0's JSON line and return the launcher's exit
+    code.  Counting devices does not initialise the GPU runtime."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SRHIP_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stdout.write(proc.stdout)
+        print(f"bench.py: the {args.gpus}-rank run failed (exit code {proc.returncode})", file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     if os.environ.get("SRHIP_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SRHIP_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}", file=sys.stderr, flush=True)
+        sys.exit(2)
+    backend = os.environ.get("SRHIP_DIST_BACKEND", "nccl") if world > 1 else None
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr, flush=True)
+        sys.exit(2)
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     dist = None
@@ -456,16 +546,16 @@ def main():
         import torch.distributed as dist
         # RCCL ("nccl") with one GPU per rank; SRHIP_DIST_BACKEND=gloo rehearses the multi-rank path on a
         # box with fewer GPUs than ranks (ranks then share a device)
-        backend = os.environ.get("SRHIP_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    args.ranks_info = {"ranks": dist.get_world_size() if dist is not None else 1, "backend": backend}
 
     if args.workload == "train":
         res = run_train(args, world, rank, dev, dist)
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(args, res)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -478,14 +568,14 @@ def main():
         ops = bench_memops.suite(verbose=False)
         warp = next(o for o in ops if o["op"].startswith("warp bilinear f32"))
         if rank == 0:
-            print(json.dumps({"metric": "algorithmic GB/s of the HBM-bound operators (warp of the previous 4K output first)",
+            emit(args, {"metric": "algorithmic GB/s of the HBM-bound operators (warp of the previous 4K output first)",
                               "value": warp["gbps"], "unit": "GB/s", "n_gpus": 1, "steps": 10, "warmup": 3, "ms_per_step": warp["ms"],
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": "backward warp of a 3-channel fp32 2160x3840 frame by per-pixel motion vectors "
                                                      "(bilinear, align_corners=True) and the other memory-bound operators at the 4K shapes"},
                               "roofline": {"bound": "hbm", "kernel": "sample_f32_kernel<1> (backward warp)", "achieved": warp["gbps"],
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": warp["gbps"] / HBM_PEAK_GBS, "traffic": None},
-                              "ops": ops}), flush=True)
+                              "ops": ops})
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -493,7 +583,7 @@ def main():
     if args.workload == "reprfn_train":
         res = run_reprfn_train(args, world, rank, dev, dist)
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(args, res)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -501,7 +591,7 @@ def main():
     if args.workload in ("temporal", "reprfn"):
         res = run_aux_infer(args, world, rank, dev, dist)
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(args, res)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -544,9 +634,9 @@ def main():
         del out
         torch.cuda.empty_cache()
         try:
-            train = run_train(args, world, rank, dev, dist, steps=args.train_steps, warmup=2, with_cpu=False)
+            train = run_train(args, world, rank, dev, dist, steps=args.train_steps, warmup=2, with_cpu=True)
             if train is not None:
-                train = {k: train[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "roofline")}
+                train = {k: train[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "roofline", "cpu_baseline") if k in train}
         except Exception as e:  # the headline line must still be printed
             if world > 1:
                 raise       # a rank that dropped out of a collective cannot be papered over
@@ -574,7 +664,7 @@ def main():
             res["train"] = train   # second half of the metric: train crops/s at this GPU count (weak scaling)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_crop)
-        print(json.dumps(res), flush=True)
+        emit(args, res)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -61,14 +61,19 @@ def save_reference_checkpoint(model: nn.Module, directory: Union[str, os.PathLik
                               global_step: Optional[int] = None, optimizer=None, scheduler=None) -> str:
     """Write a checkpoint the reference trainer can resume from (core/trainer.py:222-240, 258-266): CPU tensors under
     ``state_dict``; with an optimizer also ``epoch``, ``global_step``, ``model``, ``optimizer``, ``scheduler`` and the
-    ``_last`` file name.  Returns the path."""
+    ``_last`` file name.  Returns the path.  The reference's ``load_checkpoint`` (core/trainer.py:271-283) evaluates
+    ``ckpt["epoch"] + 1`` and feeds ``ckpt["scheduler"]`` to the scheduler, so a resumable file needs all three of
+    ``epoch``, ``global_step`` and ``scheduler``: a call with an optimizer but without them raises ``ValueError``."""
+    if optimizer is not None and (epoch is None or global_step is None or scheduler is None):
+        raise ValueError("save_reference_checkpoint: a resumable checkpoint (optimizer given) needs epoch, global_step and "
+                         "scheduler as well; omit the optimizer to write a plain state-dict file")
     target = model.module if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else model
     state = OrderedDict((k, v.detach().cpu()) for k, v in target.state_dict().items())
     ckpt: Dict[str, Any] = {"state_dict": state}
     last = optimizer is not None
     if last:
         ckpt.update({"epoch": epoch, "global_step": global_step, "model": state, "optimizer": optimizer.state_dict(),
-                     "scheduler": None if scheduler is None else scheduler.state_dict()})
+                     "scheduler": scheduler.state_dict()})
     path = os.path.join(os.fspath(directory), checkpoint_name(target, sr_scale, None if last else epoch, global_step))
     torch.save(ckpt, path)
     return path

@@ -25,6 +25,8 @@
 //     major read back, bias, activation, scale, residual, bf16 pack, 16-byte whole-pixel stores)
 //     and all per-row issue work (LDS-DMA pieces, residual loads) are micro-steps interleaved with
 //     the MFMAs of the NEXT row, so they hide in the matrix pipe's shadow.
+#include <atomic>
+
 #include "srhip_common.h"
 
 namespace {
@@ -691,7 +693,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, unsigned short*
 template <class C>
 int launch_conv(ConvParams p, hipStream_t stream)
 {
-    static int blocks_per_cu = 0;  // immutable after first call for this instantiation
+    // per device, immutable after the first call on that device for this instantiation
+    static std::atomic<int> blocks_per_cu_dev[kSrhipMaxDevices];
+    const int dev = srhip_current_device();
+    int blocks_per_cu = blocks_per_cu_dev[dev].load(std::memory_order_acquire);
     if (blocks_per_cu == 0) {
         if (C::LDS_BYTES > 48 * 1024) {
             if (hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -705,6 +710,7 @@ int launch_conv(ConvParams p, hipStream_t stream)
                 hipSuccess || nb < 1)
             nb = 1;
         blocks_per_cu = nb > 2 ? 2 : nb;
+        blocks_per_cu_dev[dev].store(blocks_per_cu, std::memory_order_release);
     }
     // ---- work decomposition: items = images x vertical segments x strips ----
     const int ncu = srhip_num_cus();

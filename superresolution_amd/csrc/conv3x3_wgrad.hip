@@ -23,6 +23,8 @@
 //   * LDS image [pixel][channel]; for 64-channel rows the two 64-byte halves of a pixel are swapped
 //     on every second pixel pair (applied on the SOURCE side of the DMA) so that the transposing
 //     reads of 4 consecutive pixels x 32 channels touch every bank once.
+#include <atomic>
+
 #include "srhip_common.h"
 
 namespace {
@@ -408,15 +410,16 @@ template <class C>
 int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int ci_real, int co_real, int accumulate,
                  float scale, hipStream_t stream)
 {
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured_dev[kSrhipMaxDevices];   // per device
+    const int dev = srhip_current_device();
+    if (!configured_dev[dev].load(std::memory_order_acquire)) {
         if (C::LDS_BYTES > 48 * 1024 &&
             hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
             srhip_set_error("conv3x3_wgrad: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);
             return SRHIP_ERR_LAUNCH;
         }
-        configured = true;
+        configured_dev[dev].store(true, std::memory_order_release);
     }
     const int slots = srhip_num_cus();
     const int nstrips = srhip_div_up(p.w, C::TW);

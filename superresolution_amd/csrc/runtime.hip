@@ -24,10 +24,17 @@ int srhip_check_launch(const char* what)
 }
 
 namespace {
-constexpr int kMaxDevices = 64;
+constexpr int kMaxDevices = kSrhipMaxDevices;
 std::mutex g_mu;
 int g_cus[kMaxDevices] = {};
 }  // namespace
+
+int srhip_current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    return dev;
+}
 
 int srhip_num_cus()
 {

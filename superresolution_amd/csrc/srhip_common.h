@@ -37,6 +37,8 @@ __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v 
 void srhip_set_error(const char* fmt, ...);
 int srhip_check_launch(const char* what);           // hipGetLastError -> status
 int srhip_num_cus();
+constexpr int kSrhipMaxDevices = 64;
+int srhip_current_device();                         // hipGetDevice, clamped to [0, kSrhipMaxDevices)
 
 #define SRHIP_REQUIRE(cond, ...)                      \
     do {                                              \

@@ -1,14 +1,19 @@
-"""Data parallelism for the training path: one process per GPU, identical replicas, one
-sum-all-reduce of the gradients per optimiser step (RCCL through ``torch.distributed``; ``gloo`` on
-CPU for tests).  The reference trains on a single device (core/trainer.py:143-161); samples are
-independent (no batch statistics anywhere on the path), so the gradient all-reduce is the only
-exchange the path needs.
+"""Data parallelism for the training path: one process per GPU, identical replicas, sum-all-reduce
+of gradient buckets per optimiser step (RCCL through ``torch.distributed``; ``gloo`` on CPU for
+tests).  The reference trains on a single device (core/trainer.py:143-161); samples are independent
+(no batch statistics anywhere on the path), so the gradient all-reduce is the only exchange the path
+needs.
 
 All parameter gradients live in ONE flat fp32 buffer (3.65 MB for the default network) and every
-``p.grad`` is a view into it: backward writes in place, the all-reduce is a single collective with
-no packing copies, and the 1/world factor is applied to the flat buffer once.
+``p.grad`` is a view into it: backward writes in place and the collectives need no packing copies.
+The buffer is cut into ``buckets`` contiguous ranges of whole parameters.  A backward that knows the
+reducer (``attach``: the default network's hand-written backward) writes each weight gradient
+straight into its view, tells the reducer (``mark_ready``), and the reducer starts the asynchronous
+all-reduce of a bucket as soon as its last gradient has been queued, so the collective runs on the
+communication stream beside the rest of the backward pass.  ``all_reduce()`` after backward starts
+whatever is still pending, waits, and applies the 1/world factor to the buffer once.
 """
-from typing import Iterable, List
+from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -16,44 +21,127 @@ from torch import Tensor
 
 
 class FlatGradAllReducer:
-    """``gather=False`` (default): every ``p.grad`` is a view of the bucket all the time and backward accumulates into
-    it in place (one small add kernel per parameter).  ``gather=True`` is for networks with hundreds of small
-    parameters (RepRFN's training form has 264): ``zero_grad`` drops the gradients, backward hands each parameter its
-    gradient tensor without a copy, and ``all_reduce`` first moves them all into the bucket with one multi-tensor copy
-    and re-points ``p.grad`` at the views, so that the optimiser still reads the bucket."""
+    """``gather=False`` (default): every ``p.grad`` is a view of the flat buffer all the time and backward accumulates
+    into it in place.  ``gather=True`` is for networks with hundreds of small parameters (RepRFN's training form has
+    264): ``zero_grad`` drops the gradients, backward hands each parameter its gradient tensor without a copy, and
+    ``all_reduce`` first moves them all into the buffer with one multi-tensor copy and re-points ``p.grad`` at the
+    views, so that the optimiser still reads the buffer.
 
-    def __init__(self, params: Iterable[Tensor], process_group=None, gather: bool = False) -> None:
+    ``buckets``: number of contiguous ranges the buffer is reduced in (whole parameters, about equal bytes).
+    ``force_collective``: run the collectives even with one rank (tests: proves the RCCL branch on a single GPU)."""
+
+    def __init__(self, params: Iterable[Tensor], process_group=None, gather: bool = False, buckets: int = 1,
+                 force_collective: bool = False) -> None:
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGradAllReducer: no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("FlatGradAllReducer: parameters must share one device and dtype")
+        if buckets < 1:
+            raise ValueError("FlatGradAllReducer: buckets must be >= 1")
         self.group = process_group
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
         self.gather = gather
+        self.force_collective = force_collective
         self.views: List[Tensor] = []
+        self._index: Dict[int, int] = {}
+        offs = []
         off = 0
-        for p in self.params:
+        for i, p in enumerate(self.params):
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             p.grad = None if gather else self.views[-1]
+            self._index[id(p)] = i
+            offs.append(off)
             off += p.numel()
+        # bucket b = parameters [first_b, first_{b+1}): cut where the running size passes b/buckets of the total
+        total = off
+        self.bucket_of: List[int] = []
+        b = 0
+        for i, p in enumerate(self.params):
+            if b + 1 < buckets and offs[i] >= (b + 1) * total / buckets:
+                b += 1      # at most one step per parameter: no bucket is ever empty
+            self.bucket_of.append(b)
+        self.n_buckets = max(self.bucket_of) + 1
+        self.bucket_range: List[tuple] = []
+        for b in range(self.n_buckets):
+            idx = [i for i, bb in enumerate(self.bucket_of) if bb == b]
+            lo, hi = offs[idx[0]], offs[idx[-1]] + self.params[idx[-1]].numel()
+            self.bucket_range.append((lo, hi))
+        self._pending = [sum(1 for bb in self.bucket_of if bb == b) for b in range(self.n_buckets)]
+        self._left = list(self._pending)
+        self._ready = [False] * len(self.params)
+        self._works: List[Optional[object]] = [None] * self.n_buckets
+        self._launched = [False] * self.n_buckets
+        self.launch_log: List[int] = []   # buckets in the order their collective was started (tests, profiling)
 
+    # ------------------------------------------------------------------ bookkeeping
     @property
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def _collective_needed(self) -> bool:
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.world_size > 1 or self.force_collective
+
+    def attach(self, module: torch.nn.Module) -> "FlatGradAllReducer":
+        """Let ``module``'s own backward write gradients straight into the views (``grad_view`` / ``mark_ready``)."""
+        module._grad_reducer = self
+        return self
+
+    def grad_view(self, p: Tensor) -> Optional[Tensor]:
+        i = self._index.get(id(p))
+        return None if i is None else self.views[i]
+
     def zero_grad(self) -> None:
-        """Replaces ``optimizer.zero_grad()``: keeps the views and zeroes the bucket, or (gather mode) drops the
-        gradients so that backward assigns instead of accumulating."""
+        """Replaces ``optimizer.zero_grad()``: keeps the views and zeroes the buffer, or (gather mode) drops the
+        gradients so that backward assigns instead of accumulating.  Also re-arms the buckets."""
         if self.gather:
             for p in self.params:
                 p.grad = None
         else:
             self.flat.zero_()
+        self._left = list(self._pending)
+        self._ready = [False] * len(self.params)
+        self._works = [None] * self.n_buckets
+        self._launched = [False] * self.n_buckets
+        self.launch_log = []
+
+    def mark_ready(self, p: Tensor) -> None:
+        """The gradient of ``p`` for this step is complete in its view (all kernels that write it are queued on the
+        current stream).  Starts the bucket's all-reduce when it was the bucket's last one."""
+        i = self._index.get(id(p))
+        if i is None or self._ready[i]:
+            return
+        self._ready[i] = True
+        b = self.bucket_of[i]
+        self._left[b] -= 1
+        if self._left[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b: int) -> None:
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        self.launch_log.append(b)
+        if not self._collective_needed():
+            return
+        lo, hi = self.bucket_range[b]
+        chunk = self.flat[lo:hi]
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal of the multi-rank path without RCCL (ranks sharing a GPU): gloo's own device path can stall
+            # behind a busy GPU, so the bucket crosses through host memory
+            host = chunk.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            chunk.copy_(host)
+        else:
+            # RCCL: the collective is queued on the process group's communication stream behind everything the current
+            # stream holds so far, and runs beside the kernels queued after this call
+            self._works[b] = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def collect(self) -> None:
-        """Gather mode: move the gradients backward produced into the bucket (parameters without one get zeros)."""
+        """Gather mode: move the gradients backward produced into the buffer (parameters without one get zeros)."""
         src, dst = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is v:
@@ -75,41 +163,49 @@ class FlatGradAllReducer:
                                    "(use FlatGradAllReducer.zero_grad, not set_to_none)")
 
     def all_reduce(self) -> None:
-        """Average the gradients over the ranks (call after backward, before optimizer.step)."""
+        """Average the gradients over the ranks (call after backward, before optimizer.step): starts the buckets
+        backward did not announce, waits for all of them, scales once."""
         if self.gather:
             self.collect()
-        w = self.world_size
-        if w == 1:
+        for b in reversed(range(self.n_buckets)):   # backward fills the buffer from its end
+            self._launch(b)
+        if not self._collective_needed():
             return
-        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
-            # rehearsal of the multi-rank path without RCCL (ranks sharing a GPU): gloo's own device path can stall
-            # behind a busy GPU, so the bucket crosses through host memory
-            host = self.flat.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.copy_(host)
-        else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.mul_(1.0 / w)
+        for wk in self._works:
+            if wk is not None:
+                wk.wait()   # RCCL: the current stream waits for the communication stream; gloo: blocks the host
+        self._works = [None] * self.n_buckets
+        w = self.world_size
+        if w > 1:
+            self.flat.mul_(1.0 / w)
 
 
-def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None) -> None:
-    """Make every replica start from rank ``src``'s parameters and buffers (one flat broadcast)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None, force_collective: bool = False) -> None:
+    """Make every replica start from rank ``src``'s parameters and buffers (one flat broadcast).  The copy back goes
+    through ``Tensor.copy_`` on the parameter itself, which bumps its version counter: packed-weight caches keyed on
+    the version see the new values."""
+    if not (dist.is_available() and dist.is_initialized()):
         return
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    if dist.get_world_size(process_group) == 1 and not force_collective:
+        return
+    tensors = list(module.parameters()) + list(module.buffers())
     if not tensors:
         return
-    flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    if flat.is_cuda and dist.get_backend(process_group) == "gloo":
-        host = flat.cpu()
-        dist.broadcast(host, src=src, group=process_group)
-        flat.copy_(host)
-    else:
-        dist.broadcast(flat, src=src, group=process_group)
-    off = 0
-    for t in tensors:
-        t.copy_(flat[off:off + t.numel()].view_as(t).to(t.dtype))
-        off += t.numel()
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+        if flat.is_cuda and dist.get_backend(process_group) == "gloo":
+            host = flat.cpu()
+            dist.broadcast(host, src=src, group=process_group)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=src, group=process_group)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t).to(t.dtype))
+            off += t.numel()
+    invalidate = getattr(module, "invalidate_packs", None)
+    if callable(invalidate):
+        invalidate()
 
 
 def shard_range(total: int, rank: int, world: int) -> range:

@@ -19,6 +19,12 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def invalidate_pack_cache() -> None:
+    """Drop every cached packed-weight copy made by conv2d_auto / conv_transpose2x2s2_auto.  The cache is keyed on each
+    weight tensor's version counter, which in-place writes through ``Parameter.data`` do not bump."""
+    _pack_cache.clear()
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -26,6 +32,10 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise ValueError(f"{name}: expected a tensor on the GPU (libsrhip has no CPU path)")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's stream: a tensor elsewhere would be read from the wrong GPU
+        raise ValueError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                         "(wrap the call in torch.cuda.device(tensor.device))")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     return t.contiguous()

@@ -98,6 +98,11 @@ class SuperSampler(nn.Module):
             self._packs[key] = hit
         return hit[1]
 
+    def invalidate_packs(self) -> None:
+        """Drop every packed-weight copy.  The cache is keyed on each weight's version counter, which in-place writes
+        through ``Parameter.data`` (some EMA / clamping code) do not bump: call this after such a write."""
+        self._packs.clear()
+
     def _pack(self, name: str, conv: nn.Conv2d, cin_a: int, ca_pad: int, cin_b: int = 0, cb_pad: int = 0) -> Tensor:
         w = conv.weight
         return self._cached_pack(name, w, lambda: F_.conv3x3_pack_weights(w.detach(), cin_a, ca_pad, cin_b, cb_pad))

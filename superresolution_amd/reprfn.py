@@ -272,6 +272,16 @@ class RepRFN(nn.Module):
         self._packs = {}
 
     # ------------------------------------------------------------------ packed-weight cache
+    def invalidate_packs(self) -> None:
+        """Drop every packed-weight copy and every cached merged RepBlock kernel.  The caches are keyed on the
+        parameters' version counters, which in-place writes through ``Parameter.data`` do not bump: call this after
+        such a write."""
+        self._packs.clear()
+        for m in self.modules():
+            if hasattr(m, "_eq_cache"):
+                object.__setattr__(m, "_eq_cache", None)
+        F_.invalidate_pack_cache()
+
     def _conv(self, key: str, weight: Tensor, bias: Tensor, x: Tensor, cin: int, **kw) -> Tensor:
         tag = (weight._version, weight.data_ptr(), weight.device)
         hit = self._packs.get(key)

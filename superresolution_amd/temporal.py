@@ -7,19 +7,17 @@ the same module tree (hence identical ``state_dict`` keys/shapes and seed-for-se
 
 Execution (inference; raises under autograd): every convolution, transposed convolution, pixel
 (un)shuffle, warp, x2 up-sampling and the gradient map run on the HIP kernels, activations NHWC
-bf16.  3x3 / stride-1 layers with at most 64 input channels go to the MFMA kernel, the other
-shapes (1x1, stride 2, wider inputs; all at low resolution) to the direct kernel.  The disocclusion
-masks (model_final.py:53-139), the depth clamp (:40-46) and the attention mix (:422) are element-wise
-/ neighbourhood logic composed from torch tensor operations on the GPU, exactly as the reference
-writes them.  The warp is ``tools_math.backward_warping`` (the reference's own helper raises for every
-input; see that module).
+bf16.  Every convolution goes to the MFMA kernel through ``functional.conv2d_auto`` (1x1, stride-2 and
+wide layers included; transposed 2x2 convolutions as 1x1 layers plus a depth-to-space copy).  The
+disocclusion masks with the marked history and auxiliary planes (model_final.py:53-139,472-486,501-504)
+are ONE fused kernel (``functional.disocclusion``), the depth clamp (:40-46) ``functional.clamp_depth``
+and the gated sum of the main stage (:422) ``functional.attention_fuse``.  The warp is
+``tools_math.backward_warping`` (the reference's own helper raises for every input; see that module).
 """
-import math
 from typing import Tuple
 
 import torch
 from torch import Tensor, nn
-from torch.nn import functional as TF
 
 from . import functional as F_
 from .tools_math import backward_warping_history
@@ -231,62 +229,6 @@ class MainNetwork(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
-# disocclusion logic of the reference written with tensor operations: the readable statement of what the fused
-# kernel (functional.disocclusion) computes; the CPU suite pins these against the reference's outputs
-# ------------------------------------------------------------------------------------------------
-def clamp_depth(depth: Tensor, thres1: float = 3.0, thres2: float = 7.0) -> Tensor:
-    """model_final.py:40-46 without the host-side max() test (the formula is the identity below thres1)."""
-    return torch.where(depth >= thres2, thres1 + math.log2(thres2 - thres1) + torch.log10((depth - thres2) + 1),
-                       torch.where(depth >= thres1, thres1 + torch.log2((depth - thres1) + 1), depth))
-
-
-def _unfold_reflect(x: Tensor, ksize: int) -> Tensor:
-    pad = ksize // 2
-    xp = TF.pad(x, (pad, pad, pad, pad), mode="reflect")
-    return xp.unfold(2, ksize, 1).unfold(3, ksize, 1).reshape(*x.shape, ksize * ksize)
-
-
-def rgb_colour_distance(rgb1: Tensor, rgb2: Tensor) -> Tensor:
-    """core/tools/color.py:22-31 (including its channel naming: index 1 is called b, index 2 g)."""
-    r1, b1, g1 = rgb1[:, 0:1], rgb1[:, 1:2], rgb1[:, 2:3]
-    r2, b2, g2 = rgb2[:, 0:1], rgb2[:, 1:2], rgb2[:, 2:3]
-    r = (r1 + r2) / 2
-    dr, dg, db = r1 - r2, g1 - g2, b1 - b2
-    return torch.sqrt((2 + r) * dr ** 2 + 4 * dg ** 2 + (2 + (1 - r)) * db ** 2)
-
-
-def compute_mask_frame(current_frame: Tensor, history_frame: Tensor, ksize: int = 3) -> Tensor:
-    u = _unfold_reflect(current_frame, ksize)[:, None, ...]
-    mask = (history_frame < u.min(dim=-1)[0]) | (history_frame > u.max(dim=-1)[0])
-    return torch.all(mask, dim=2, keepdim=True)
-
-
-def compute_mask_basecolor(current_color: Tensor, history_color: Tensor, ksize: int = 3) -> Tensor:
-    b, f, c, h, w = history_color.shape
-    cur = _unfold_reflect(current_color.reshape(b * f, c, h, w), ksize)
-    hist = history_color.reshape(b * f, c, h, w)[..., None]
-    dist = rgb_colour_distance(cur, hist).view(b, f, 1, h, w, ksize * ksize)
-    return (dist > 0.5).float().mean(dim=-1) > 0.7
-
-
-def compute_mask_depth(current_depth: Tensor, history_depth: Tensor) -> Tensor:
-    return (current_depth - history_depth) > (0.1 * current_depth)
-
-
-def compute_mask_normal(current_normal: Tensor, history_normal: Tensor, thres: float = 0.707) -> Tensor:
-    dot = torch.sum(((current_normal - 0.5) * 2.0) * ((history_normal - 0.5) * 2.0), dim=2, keepdim=True)
-    return torch.logical_not(dot.abs() < 1e-3) & (dot < thres)
-
-
-def compute_mask_metallic(cur: Tensor, hist: Tensor, mark_max_value: float = 1000.0) -> Tensor:
-    return (cur > mark_max_value) | (torch.abs(cur - hist) > 0.25)
-
-
-def compute_mask_roughness(cur: Tensor, hist: Tensor, mark_min_value: float = -1000.0) -> Tensor:
-    return (cur < mark_min_value) | (torch.abs(cur - hist) > 0.25)
-
-
-# ------------------------------------------------------------------------------------------------
 class SuperSampler(nn.Module):
     def __init__(self, frame_ch: int, buffer_ch: int, sr_scale: int, n_history: int) -> None:
         super().__init__()
@@ -313,6 +255,12 @@ class SuperSampler(nn.Module):
                 nn.init.xavier_normal_(m.weight)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
+
+    def invalidate_packs(self) -> None:
+        """Drop every packed-weight copy (keyed on the parameters' version counters, which in-place writes through
+        ``Parameter.data`` do not bump)."""
+        F_.invalidate_pack_cache()
+        object.__setattr__(self.buffers_encoder, "_enhance_cache", None)
 
     def forward(self, lr_frame: Tensor, hr_buffer: Tensor, lr_buffer: Tensor, motion_vectors: Tensor,
                 history_frames: Tensor, history_buffer: Tensor) -> Tuple[Tensor, Tensor]:

@@ -12,7 +12,8 @@ def test_round_trip_in_the_trainer_format(tmp_path):
     m = SuperSampler(3, 10, 1)
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
     p1 = C.save_reference_checkpoint(m, tmp_path, 4, epoch=3, global_step=1200)
-    p2 = C.save_reference_checkpoint(m, tmp_path, 4, epoch=3, global_step=1200, optimizer=opt)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 10000, 0.98)      # configs/trainer/4x_H2.yaml:18-23
+    p2 = C.save_reference_checkpoint(m, tmp_path, 4, epoch=3, global_step=1200, optimizer=opt, scheduler=sched)
     assert os.path.basename(p1) == "SuperSampler_4x_epoch-3_steps-1200.ckpt"      # trainer.py:229
     assert os.path.basename(p2) == "SuperSampler_4x_last.ckpt"                     # trainer.py:227
     raw = torch.load(p2, weights_only=True)
@@ -22,6 +23,33 @@ def test_round_trip_in_the_trainer_format(tmp_path):
     assert C.load_reference_checkpoint(n, p1) == ([], [])
     for (ka, a), (kb, b) in zip(m.state_dict().items(), n.state_dict().items()):
         assert ka == kb and torch.equal(a, b)
+
+
+def test_resumable_checkpoint_needs_epoch_step_scheduler_and_resumes(tmp_path):
+    """The reference's load_checkpoint (core/trainer.py:271-283) computes ckpt["epoch"] + 1, reads global_step and
+    calls scheduler.load_state_dict(ckpt["scheduler"]): a `_last` file without them cannot be resumed, so writing one
+    is refused; a complete one goes through the reference's resume logic (restated below)."""
+    import pytest
+    torch.manual_seed(1)
+    m = SuperSampler(3, 10, 1)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 10000, 0.98)
+    for kw in ({}, {"epoch": 2}, {"epoch": 2, "global_step": 7}, {"epoch": 2, "scheduler": sched}):
+        with pytest.raises(ValueError):
+            C.save_reference_checkpoint(m, tmp_path, 4, optimizer=opt, **kw)
+    path = C.save_reference_checkpoint(m, tmp_path, 4, epoch=2, global_step=7, optimizer=opt, scheduler=sched)
+    ckpt = torch.load(path, weights_only=True)
+    # core/trainer.py:273-281, step by step
+    resume_epoch = 3
+    assert int(ckpt["epoch"] + 1) == resume_epoch
+    assert int(ckpt["global_step"]) == 7
+    n = SuperSampler(3, 10, 1)
+    n.load_state_dict(ckpt["model"])
+    opt2 = torch.optim.AdamW(n.parameters(), lr=1e-4, weight_decay=1e-4)
+    sched2 = torch.optim.lr_scheduler.StepLR(opt2, 10000, 0.98)
+    opt2.load_state_dict(ckpt["optimizer"])
+    sched2.load_state_dict(ckpt["scheduler"])
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), n.state_dict().values()))
 
 
 def test_wrapper_prefixes_are_stripped(ss_golden):

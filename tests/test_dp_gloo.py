@@ -121,3 +121,70 @@ def test_gather_mode_fills_the_same_bucket():
         assert torch.equal(rb.flat[n:], torch.zeros(2))
         rb.all_reduce()                     # idempotent: nothing left to collect
         assert torch.allclose(rb.flat[:n], ra.flat, rtol=1e-6, atol=1e-7)
+
+
+def _bucket_worker(rank, world, port, q):
+    """Two ranks, the same gradients reduced three ways: one bucket after backward, three buckets started from inside
+    the backward pass in reverse parameter order (the way the default network's hand-written backward announces its
+    weight gradients), and three buckets all started after backward."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters
+        torch.manual_seed(5)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in ((7, 3), (5,), (4, 4, 3), (9,), (2, 8), (6,))]
+        versions = [p._version for p in params]
+        holder = torch.nn.ParameterList(params)
+        broadcast_parameters(holder, src=0)
+        bumped = all(p._version > v for p, v in zip(params, versions))   # packed-weight caches key on the version
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = [torch.randn(p.shape, generator=g) for p in params]
+        out = []
+        for buckets, announce in ((1, False), (3, True), (3, False)):
+            red = FlatGradAllReducer(params, buckets=buckets)
+            red.zero_grad()
+            for p, gr in reversed(list(zip(params, grads))):           # backward order = reverse parameter order
+                red.grad_view(p).add_(gr)
+                if announce:
+                    red.mark_ready(p)
+            started_in_backward = list(red.launch_log)
+            red.all_reduce()
+            out.append((red.flat.clone().numpy(), red.n_buckets, started_in_backward, list(red.launch_log)))
+        q.put((rank, bumped, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bucketed_overlapped_all_reduce_is_bit_equal_to_one_bucket():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, bumped, out in res:
+        assert bumped, "broadcast_parameters must bump the parameters' version counters"
+        (one, nb1, _, _), (over, nb3, started, log3), (late, _, started_late, log_late) = out
+        assert nb1 == 1 and nb3 == 3
+        assert started == [2, 1, 0], "buckets must start as backward completes them, last parameters first"
+        assert started_late == [] and log_late == [2, 1, 0]
+        assert (one == over).all() and (one == late).all(), "bucketing changed the reduced gradients"
+    assert (res[0][2][0][0] == res[1][2][0][0]).all(), "ranks disagree after the all-reduce"
+
+
+def test_bucket_layout_covers_the_buffer_in_whole_parameters():
+    from superresolution_amd.dp import FlatGradAllReducer
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (10, 1, 30, 5, 5, 49)]
+    red = FlatGradAllReducer(params, buckets=4)
+    assert red.bucket_range[0][0] == 0 and red.bucket_range[-1][1] == red.flat.numel()
+    for (lo, hi), (lo2, _hi2) in zip(red.bucket_range, red.bucket_range[1:]):
+        assert hi == lo2 and hi > lo
+    assert sorted(set(red.bucket_of)) == list(range(red.n_buckets)) and red.bucket_of == sorted(red.bucket_of)
+    # more buckets than parameters: never an empty bucket
+    red = FlatGradAllReducer(params[:2], buckets=8)
+    assert red.n_buckets <= 2 and all(hi > lo for lo, hi in red.bucket_range)

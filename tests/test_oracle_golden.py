@@ -150,7 +150,7 @@ def test_supersampler_backward_golden(ss_golden):
     (dL/d(sr) of L1 + 0.5*SSIM on the clipped output comes from torch's autograd of the loss mirror,
     checked here against the golden loss value)."""
     import torch
-    from superresolution_amd.loss import LossGroup
+    from oracle.torch_checkers import LossGroup
     z, sd = ss_golden
     info = {}
 
@@ -173,7 +173,7 @@ def test_loss_mirror_golden(ss_golden):
     """The torch formulation of LossGroup (the checker of the fused GPU loss) reproduces the loss values the
     reference computed on its own output."""
     import torch
-    from superresolution_amd.loss import LossGroup
+    from oracle.torch_checkers import LossGroup
     z, _ = ss_golden
     loss, d = LossGroup(1.0, 0.5)({"hr_frames": torch.from_numpy(z["hr_frames"]),
                                    "sr_frames": torch.clip(torch.from_numpy(z["sr_frames"]), 0.0, 10.0)})
@@ -223,3 +223,14 @@ def test_dilate_velocity_matches_the_reference_function():
     d = np.concatenate([z["a.depth"], z["a.depth"][:, :, ::-1].copy()])
     both = orc.dilate_velocity(m, d, 3)
     assert np.array_equal(both[0:1], z["a.out"]) and np.array_equal(both[1:2], orc.dilate_velocity(m[1:2], d[1:2], 3))
+
+
+def test_torch_operator_composition_reproduces_the_reference_forward(ss_golden):
+    """bench.py times this composition of stock torch operators as the CPU baseline: it must be the reference's graph."""
+    import torch
+    from oracle.torch_checkers import supersampler_forward_torch
+    z, sd = ss_golden
+    sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        sr = supersampler_forward_torch(sd, torch.from_numpy(z["lr_frames"])[:, -1], torch.from_numpy(z["hr_buffers"])[:, -1])
+    assert float((sr - torch.from_numpy(z["sr_frames"])).abs().max()) <= 1e-5

@@ -53,10 +53,10 @@ def test_disocclusion_oracle_matches_reference_masks():
 
 
 def test_tensor_statement_of_the_masks_matches_reference():
-    """The tensor-operation statement kept in temporal.py next to the fused kernel gives the same masks."""
+    """The tensor-operation statement of the masks (oracle/torch_checkers.py) gives the reference's masks."""
     import numpy as np
     import torch
-    from superresolution_amd import temporal as T
+    from oracle import torch_checkers as T
     z = _masks_golden()
     for t in "abc":
         lr_frame, lr_buffer = torch.from_numpy(z[t + ".lr_frame"]), torch.from_numpy(z[t + ".lr_buffer"])
