@@ -334,6 +334,17 @@ SRHIP_API int srhip_layernorm_cf_bwd_f32(const float* x, const float* weight, co
                                          float* dweight, float* dbias, void* workspace, int n, int c, int hw,
                                          float eps, void* stream);
 
+/* srhip_layernorm_cf_bwd_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels, same results;
+ * the workspace is a fixed array of device memory inside the library (8.5 MB per GPU the library runs on, held
+ * until the process ends), so the call takes no workspace and allocates nothing.  Limits: n * hw <= 1,048,576
+ * pixels and c <= 256 channels; larger shapes are rejected with SRHIP_ERR_INVALID.  Calls that overlap on one GPU
+ * (different streams or threads) share the array and race; the first call on a device looks the array's address up
+ * (hipGetSymbolAddress), so make one call outside a stream capture before capturing. */
+SRHIP_API int srhip_layernorm_cf_bwd_f32_static(const float* x, const float* weight, const float* dy, float* dx,
+                                                float* dweight, float* dbias, int n, int c, int hw, float eps,
+                                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "srhip_clamp_depth_f32": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_float, c_float, c_void_p]),
     "srhip_layernorm_cf_bwd_workspace_bytes": (c_size_t, [c_int] * 3),
     "srhip_layernorm_cf_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 3 + [c_float, c_void_p]),
+    "srhip_layernorm_cf_bwd_f32_static": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_float, c_void_p]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():

@@ -4,6 +4,8 @@
 // One thread moves 16 bytes wherever the layout allows it; grids are capped and grid-strided.
 #include <hip/hip_fp16.h>
 
+#include <mutex>
+
 #include "srhip_common.h"
 
 // The coordinate / index arithmetic below replays the reference's fp32 operator sequence one
@@ -1268,6 +1270,52 @@ SRHIP_API int srhip_layernorm_cf_bwd_f32(const float* x, const float* weight, co
     hipLaunchKernelGGL(layernorm_cf_bwd_param_kernel, dim3(c, kLnSlices), dim3(256), 0, s, x, dy, stats, partial, n, c, (long long)hw);
     hipLaunchKernelGGL(layernorm_cf_bwd_final_kernel, dim3(srhip_div_up(c, 64)), dim3(64), 0, s, partial, dweight, dbias, c);
     return srhip_check_launch("layernorm_cf_bwd_f32");
+}
+
+// ---- the same backward for callers that must not allocate: its workspace is a fixed array in device memory.
+// Each GPU the library runs on holds its own copy of the array (8.5 MB) at its own address until the process ends.
+constexpr long long kLnStaticMaxPixels = 1ll << 20;   // n * hw
+constexpr int kLnStaticMaxChannels = 256;
+static __device__ __align__(256) float g_ln_scratch[kLnStaticMaxPixels * 2 + (long long)kLnStaticMaxChannels * kLnSlices * 2];
+static std::mutex g_ln_scratch_mu;
+static float* g_ln_scratch_ptr[kSrhipMaxDevices] = {};   // device address of the array, per device
+
+SRHIP_API int srhip_layernorm_cf_bwd_f32_static(const float* x, const float* weight, const float* dy, float* dx,
+                                                float* dweight, float* dbias, int n, int c, int hw, float eps,
+                                                void* stream)
+{
+    SRHIP_REQUIRE(x && weight && dy && dx && dweight && dbias, "layernorm_cf_bwd_f32_static: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && hw >= 1, "layernorm_cf_bwd_f32_static: bad shape");
+    SRHIP_REQUIRE((long long)n * hw <= kLnStaticMaxPixels && c <= kLnStaticMaxChannels,
+                  "layernorm_cf_bwd_f32_static: n*hw = %lld pixels / %d channels exceed the fixed scratch (at most %lld pixels, "
+                  "%d channels); use srhip_layernorm_cf_bwd_f32 with a caller-owned workspace",
+                  (long long)n * hw, c, kLnStaticMaxPixels, kLnStaticMaxChannels);
+    const int dev = srhip_current_device();
+    float* scratch = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ln_scratch_mu);
+        if (g_ln_scratch_ptr[dev] == nullptr) {
+            // the array's name is a host-side handle, not a device address: ask the runtime where THIS device keeps it
+            float* ptr = nullptr;
+            const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(g_ln_scratch));
+            if (e != hipSuccess || ptr == nullptr) {
+                srhip_set_error("layernorm_cf_bwd_f32_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+                return SRHIP_ERR_LAUNCH;
+            }
+            g_ln_scratch_ptr[dev] = ptr;
+        }
+        scratch = g_ln_scratch_ptr[dev];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // every word the later kernels read is written first by this call (stats for all n*hw pixels, then all
+    // c * kLnSlices partials): the previous call's contents never need clearing
+    float* stats = scratch;
+    float* partial = scratch + (size_t)n * hw * 2;
+    hipLaunchKernelGGL(layernorm_cf_bwd_dx_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0, s,
+                       x, weight, dy, dx, stats, n, c, (long long)hw, eps);
+    hipLaunchKernelGGL(layernorm_cf_bwd_param_kernel, dim3(c, kLnSlices), dim3(256), 0, s, x, dy, stats, partial, n, c, (long long)hw);
+    hipLaunchKernelGGL(layernorm_cf_bwd_final_kernel, dim3(srhip_div_up(c, 64)), dim3(64), 0, s, partial, dweight, dbias, c);
+    return srhip_check_launch("layernorm_cf_bwd_f32_static");
 }
 
 SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, int cpad,
