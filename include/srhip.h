@@ -115,6 +115,28 @@ SRHIP_API int srhip_conv3x3_pack_weights(const float* w, void* wpack, int w_o, i
 
 SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* args, void* stream);
 
+/* The two chained 64 -> 64 3x3 convolutions of a residual block as ONE launch:
+ *   mid = ReLU(conv1(src) + bias1);   dst = alpha * act2(conv2(mid) + bias2) + src
+ * SRResidualBlock (core/models/model.py:22-33: act2 none, alpha 0.2) and Residual(ConvActivation, ConvActivation)
+ * (core/models/model.py:17-19,70-73: act2 ReLU, alpha 1).  `mid` stays in LDS: the pair moves 256 bytes of HBM traffic
+ * per pixel instead of the 640 of two srhip_conv3x3_fwd launches, and gives the same values (the same bf16 rounding of
+ * `mid`).  If `mid` is not NULL the kernel also writes it (training keeps it for the backward pass): 384 bytes per pixel.
+ * All tensors (N,H,W,64) bf16 NHWC, pairwise distinct; wpack1 / wpack2 from srhip_conv3x3_pack_weights(64 -> 64). */
+typedef struct {
+    const void* src;
+    const void* wpack1;
+    const float* bias1;   /* fp32[64] or NULL */
+    const void* wpack2;
+    const float* bias2;   /* fp32[64] or NULL */
+    void* mid;            /* NULL, or receives ReLU(conv1(src) + bias1) */
+    void* dst;
+    int n, h, w;
+    int act2;             /* srhip_act of the second layer */
+    float slope2;         /* its LeakyReLU slope */
+    float alpha;          /* > 0 */
+} srhip_conv3x3_pair_args;
+SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* args, void* stream);
+
 /* Weight and bias gradient of the same layer (autograd backward of nn.Conv2d,
  * core/models/model.py:12,26-28,112-114 via loss.backward() at core/trainer.py:160):
  *   dw[co][ci_off+ci][ky][kx] (=|+=) scale * sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]

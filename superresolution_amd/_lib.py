@@ -46,6 +46,16 @@ class Conv3x3Args(ctypes.Structure):
     ]
 
 
+class Conv3x3PairArgs(ctypes.Structure):
+    """srhip_conv3x3_pair_args"""
+    _fields_ = [
+        ("src", c_void_p), ("wpack1", c_void_p), ("bias1", c_void_p), ("wpack2", c_void_p), ("bias2", c_void_p),
+        ("mid", c_void_p), ("dst", c_void_p),
+        ("n", c_int), ("h", c_int), ("w", c_int),
+        ("act2", c_int), ("slope2", c_float), ("alpha", c_float),
+    ]
+
+
 _SIGNATURES = {
     "srhip_version": (c_int, []),
     "srhip_last_error": (ctypes.c_char_p, []),
@@ -55,6 +65,7 @@ _SIGNATURES = {
     "srhip_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p]),
     "srhip_conv3x3_fwd": (c_int, [ctypes.POINTER(Conv3x3Args), c_void_p]),
+    "srhip_conv3x3_pair_fwd": (c_int, [ctypes.POINTER(Conv3x3PairArgs), c_void_p]),
     "srhip_conv3x3_wgrad_workspace_bytes": (c_size_t, []),
     "srhip_conv3x3_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float, c_void_p]),
     "srhip_conv2d_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 +

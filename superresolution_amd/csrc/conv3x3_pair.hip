@@ -1,0 +1,658 @@
+// Two chained 3x3 / stride 1 / pad 1 convolutions of a 64-channel residual block as ONE kernel for gfx950:
+//
+//     mid = ReLU(conv1(x) + b1)                       (never leaves the chip unless the caller asks for it)
+//     dst = alpha * act2(conv2(mid) + b2) + x
+//
+// i.e. SRResidualBlock (act2 none, alpha 0.2) and Residual(ConvActivation, ConvActivation) (act2 ReLU, alpha 1) of the
+// reference's default network.  As two launches the pair moves 128 + 128 (first layer) + 128 + 128 + 128 (second
+// layer with its residual) = 640 bytes of HBM traffic per pixel; fused it reads x once and writes dst once: 256.
+//
+// Structure: the streaming implicit GEMM of conv3x3_mfma.hip (one wave per SIMD, a layer's whole weight tensor pinned
+// in the wave's registers, input rows flowing HBM -> LDS by LDS-DMA a few rows ahead, v_mfma_f32_32x32x16_bf16 with
+// A = weights and B = 32 pixels), with the four waves of a workgroup SPECIALISED: waves 0-1 hold the first layer's
+// weights and produce rows of `mid` for 64 columns into an LDS ring (bias through the accumulator's initial value,
+// ReLU and the zero padding of `mid` outside the image applied on packed bf16 pairs, written pixel-major with the same
+// XOR swizzle the LDS-DMA gives the x rows); waves 2-3 hold the second layer's weights, read `mid` rows from that ring
+// exactly as the first layer reads x rows, and run the single-layer kernel's epilogue (fp32 staging through LDS,
+// bias / alpha / activation / residual, 16-byte whole-pixel stores).  The second layer runs four rows behind the first:
+// one barrier per row step hands a finished `mid` row over.  A strip yields 62 output columns (the first layer
+// computes the 64 `mid` columns they need, from 66 columns of x); a vertical segment of R rows costs R + 2 rows of
+// first-layer work.
+//
+// Every vector-memory operation and every LDS read is asm with a COUNTED wait, as in the single-layer kernel; the same
+// fence discipline applies (tools/isa_lint.py checks it).
+#include <atomic>
+
+#include "conv_mfma_util.h"
+#include "srhip_common.h"
+
+namespace {
+
+struct PairParams {
+    const char* src;
+    const bf16x8* wpack1;
+    const float* bias1;
+    const bf16x8* wpack2;
+    const float* bias2;
+    char* mid;
+    char* dst;
+    int n, h, w;
+    float slope2, alpha;
+    int nstrips, nsegs, seg_h, total_items;
+};
+
+struct PairCfg {
+    static constexpr int CH = 64;                      // channels of x, mid and dst
+    static constexpr int KC = 4, NCT = 2;              // 16-channel K planes, 32-wide output-channel tiles
+    static constexpr int MPT = KC * NCT;               // MFMAs per tap
+    static constexpr int TWO = 62;                     // output columns per strip
+    static constexpr int XPX = 66;                     // x columns per row held in LDS (mid: 64)
+    static constexpr int PITCH = 72;                   // pixels per LDS row image (whole 1-KiB pieces)
+    static constexpr int SLOT_BYTES = PITCH * CH * 2;  // 9216
+    static constexpr int NPIECE = SLOT_BYTES / 1024;   // 9 LDS-DMA pieces per x row
+    static constexpr int MAXP = 5;                     // pieces per first-layer wave per row (wave w: w, w+2, ..., w+8)
+    static constexpr int LA = 5;                       // x rows fetched ahead of the row being computed
+    static constexpr int RING = LA + 1;                // x row slots
+    static constexpr int NY = 4;                       // mid row slots
+    static constexpr int LAG = 4;                      // the second layer computes output row s - LAG in step s
+    static constexpr int XRING_BYTES = RING * SLOT_BYTES;
+    static constexpr int YRING_OFF = XRING_BYTES;
+    static constexpr int YRING_BYTES = NY * SLOT_BYTES;
+    // second layer: epilogue staging as in the single-layer kernel (32 px x 64 fp32 per wave)
+    static constexpr int NSLOT = 8 * NCT, PXS = NSLOT * 16, LPP = NSLOT / 2, PPI = 64 / LPP, NST = 2 * NCT;
+    static constexpr int STAGE_OFF = YRING_OFF + YRING_BYTES;
+    static constexpr int STAGE_BYTES = 32 * PXS;
+    static constexpr int DUMMY_OFF = STAGE_OFF + 2 * STAGE_BYTES;  // 1 KiB sink of the one DMA piece nobody owns
+    static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
+    static constexpr int NFA1 = 256 / 4;               // first layer: accumulators in VGPRs, 64 fragments in AGPRs
+    static constexpr int NFA2 = (256 - 16 * NCT) / 4;  // second layer: accumulators a[0:31], 56 fragments in AGPRs
+};
+
+// MFMA of the first layer: accumulator in VGPRs (the epilogue's vector ALU reads it directly); the first MFMA of a
+// row's chain takes the bias (accumulator order) as C.
+template <bool IN_AGPR, bool FIRST>
+__device__ __forceinline__ void mfma_vacc(f32x16& acc, const bf16x8& w, const bf16x8& b, const f32x16& cinit)
+{
+    if constexpr (IN_AGPR) {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w), "v"(b), "v"(cinit));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+    } else {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(w), "v"(b), "v"(cinit));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+    }
+}
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// ReLU on a packed pair of bf16 values: a negative bf16 is a negative int16, so max(., 0) per half clears it.
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned v)
+{
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+__device__ __forceinline__ void lds_write_b64(unsigned addr, unsigned lo, unsigned hi)
+{
+    const unsigned long long d = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(d) : "memory");
+}
+__device__ __forceinline__ u32x4 lds_read_u32x4(unsigned addr)
+{
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+
+struct PairItem {
+    int n, x0, y0, nout;
+};
+__device__ __forceinline__ PairItem pair_decode_item(const PairParams& p, int item)
+{
+    const int strip = item % p.nstrips;
+    const int tseg = item / p.nstrips;
+    const int seg = tseg % p.nsegs;
+    PairItem it;
+    it.n = tseg / p.nsegs;
+    it.x0 = strip * PairCfg::TWO;
+    it.y0 = seg * p.seg_h;
+    it.nout = min(it.y0 + p.seg_h, p.h) - it.y0;
+    return it;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Waves 0-1: first layer.  Step s computes mid row s (image row y0 - 1 + s) for the 32 columns x0 - 1 + 32 pg + pl from
+// x rows s .. s+2 of the ring; the row's epilogue (accumulators -> bf16 -> LDS) runs between the MFMAs of step s + 1.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool STORE_MID>
+__device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
+                                                 const int lane)
+{
+    using P = PairCfg;
+    const int hl = lane >> 5, pl = lane & 31;
+    // vector-memory schedule of one step: taps 0..3 [mid store of row s-2 (STORE_MID)] [DMA piece t of x row s+LA],
+    // tap 4 [DMA piece 4]; the last DMA is the last operation of the step.
+    constexpr int VM_STEP = P::MAXP + (STORE_MID ? 4 : 0);
+    constexpr int WAIT_STEADY = (P::LA - 3) * VM_STEP;                 // row s+2 was issued in step s+2-LA
+    constexpr int WAIT_EARLY = P::MAXP + VM_STEP < 2 * VM_STEP ? P::MAXP + VM_STEP : 2 * VM_STEP;
+    static_assert(WAIT_STEADY <= 63 && P::LA == 5, "vmcnt is a 6-bit field; the early-step waits assume LA = 5");
+
+    bf16x8 wreg[9][P::KC][P::NCT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kc = 0; kc < P::KC; ++kc)
+#pragma unroll
+            for (int ct = 0; ct < P::NCT; ++ct) wreg[t][kc][ct] = p.wpack1[((t * P::KC + kc) * P::NCT + ct) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // The weight loads must have landed BEFORE the row loop: a wait the compiler leaves at their first use sits between
+    // the MFMAs of every row and drains the hand-counted vector-memory queue there.  An empty asm that "uses" each
+    // fragment (in the register file it is pinned to) makes the compiler place its wait here.
+    static_for<0, 9 * P::KC * P::NCT>([&](auto f_c) {
+        SRHIP_CAPTURE(wreg);
+        constexpr int f = decltype(f_c)::value;
+        if constexpr (f < P::NFA1) asm volatile("" : "+a"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+        else asm volatile("" : "+v"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+    });
+    // bias in accumulator order: register r of tile ct <-> channel 32 ct + 8 (r >> 2) + 4 hl + (r & 3)
+    f32x16 biasv[P::NCT];
+#pragma unroll
+    for (int ct = 0; ct < P::NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            biasv[ct][r] = p.bias1 != nullptr ? p.bias1[ct * 32 + 8 * (r >> 2) + 4 * hl + (r & 3)] : 0.0f;
+
+    unsigned rd[3];  // chunk hl of LDS pixel 32 pg + pl + kx; chunk pair kc of the same pixel at rd ^ (kc << 5)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = 32 * pg + pl + kx;
+        rd[kx] = (unsigned)(px * 128 + ((hl ^ ((px >> 1) & 7)) << 4));
+    }
+    const int q = 32 * pg + pl;                                             // this lane's mid pixel in the row image
+    const unsigned wy = (unsigned)(q * 128 + 8 * hl + (((q >> 1) & 7) << 4));  // its quad (ct, g) goes to wy ^ ((4 ct + g) << 4)
+    unsigned rb[4];  // read-back for the mid store: group k = pixels 32 pg + 8 k + (lane >> 3), chunk lane & 7
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qk = 32 * pg + 8 * k + (lane >> 3);
+        rb[k] = (unsigned)(qk * 128 + (((lane & 7) ^ ((qk >> 1) & 7)) << 4));
+    }
+
+    const int H = p.h, W = p.w;
+    bf16x8 bq[2][P::KC];
+    f32x16 acc[2][P::NCT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ct = 0; ct < P::NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][ct][r] = 0.0f;
+    u32x4 midv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) midv[k] = u32x4{0u, 0u, 0u, 0u};
+    unsigned e_p0 = 0, e_p1 = 0, e_addr = 0;
+
+    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+        const PairItem it = pair_decode_item(p, item);
+        const int x0 = it.x0, y0 = it.y0, nout = it.nout;
+        const int nin = nout + 4;  // x rows rx = 0..nin-1 <-> image row y0 - 2 + rx
+        const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
+        const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
+        const __amdgpu_buffer_rsrc_t rsrc_x =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + (long long)it.n * img), 0, (int)img, 0x00020000);
+        const i32x4 mid_srd = make_srd(STORE_MID ? p.mid + (long long)it.n * img : p.dst, STORE_MID ? img : 0u);
+
+        unsigned poff[P::MAXP];
+#pragma unroll
+        for (int m = 0; m < P::MAXP; ++m) {
+            const int piece = pg + 2 * m;
+            const int j = piece * 64 + lane;
+            const int px = j >> 3;
+            const int c = (j & 7) ^ ((px >> 1) & 7);
+            const int x = x0 - 2 + px;
+            const bool ok = (x >= 0) && (x < W) && (px < P::XPX) && (piece < P::NPIECE);
+            poff[m] = ok ? (unsigned)((x * P::CH + c * 8) * 2) : kOobOffset;
+        }
+        const int ycol = x0 - 1 + q;
+        const unsigned colmask = (ycol >= 0 && ycol < W) ? 0xffffffffu : 0u;
+        unsigned mvo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int qk = 32 * pg + 8 * k + (lane >> 3);
+            const int col = x0 - 1 + qk;
+            mvo[k] = (STORE_MID && qk >= 1 && qk <= P::TWO && col < W) ? (unsigned)((col * P::CH + (lane & 7) * 8) * 2) : kOobOffset;
+        }
+
+        auto issue_piece = [&](auto m_c, const unsigned soff, const unsigned slot_off) {
+            constexpr int m = decltype(m_c)::value;
+            const int piece = pg + 2 * m;
+            const bool mine = (m < P::MAXP - 1) || (piece < P::NPIECE);
+            const unsigned off = mine ? slot_off + (unsigned)piece * 1024u : (unsigned)P::DUMMY_OFF;
+            lds_dma_b128(rsrc_x, (__attribute__((address_space(3))) void*)(smem + off), poff[m], soff);
+        };
+        auto row_soff = [&](const int rx) -> unsigned {
+            const int y = y0 - 2 + rx;
+            const bool yin = (y >= 0) & (y < H) & (rx < nin);
+            return yin ? (unsigned)y * row_pitch : kOobOffset;
+        };
+        // epilogue of one accumulator quad: four consecutive channels of this lane's pixel -> bf16, ReLU, padding mask
+        auto quad_pack = [&](const f32x16& a, auto g_c, const unsigned ymask, unsigned& o0, unsigned& o1) {
+            constexpr int g = decltype(g_c)::value;
+            o0 = relu_bf16x2(pack_bf16x2(a[4 * g + 0], a[4 * g + 1])) & ymask;
+            o1 = relu_bf16x2(pack_bf16x2(a[4 * g + 2], a[4 * g + 3])) & ymask;
+        };
+
+        int xpos = 0;  // ring slot of x row s
+        auto step = [&](auto par_c, const int s) {
+            constexpr int PAR = decltype(par_c)::value;
+            const bool compute = s < nout + 2;
+            if (compute) {
+                if (s == 0) vm_wait<0>();
+                else if (s < P::LA - 2) vm_wait<WAIT_EARLY>();
+                else vm_wait<WAIT_STEADY>();
+            }
+            __builtin_amdgcn_s_barrier();
+
+            // mid row s-1 (accumulators of the other parity) goes to slot (s-1) & 3; rows outside the image are zeros
+            const int yr = s - 1;
+            const int yimg = y0 - 1 + yr;
+            const unsigned yslot = lds_base + (unsigned)P::YRING_OFF + (unsigned)((yr & (P::NY - 1)) * P::SLOT_BYTES);
+            const unsigned ymask = (s >= 1 && yimg >= 0 && yimg < H) ? colmask : 0u;
+            const unsigned wyr = yslot + wy;
+            // mid row s-2 (read back at the end of step s-1) goes to HBM if it is one of the segment's own rows
+            const int mr = s - 2;
+            const unsigned mid_soff = (mr >= 1 && mr <= nout) ? (unsigned)(y0 - 1 + mr) * row_pitch : kOobOffset;
+
+            if (!compute) {
+                if (s == nout + 2) {
+                    // the last mid row's epilogue and the last mid store, with nothing to hide them behind
+                    static_for<0, 8>([&](auto t_c) {
+                        SRHIP_CAPTURE(acc);
+                        constexpr int t = decltype(t_c)::value;
+                        unsigned o0, o1;
+                        quad_pack(acc[PAR ^ 1][t / 4], IntC<t % 4>{}, ymask, o0, o1);
+                        lds_write_b64(wyr ^ (unsigned)((4 * (t / 4) + (t % 4)) << 4), o0, o1);
+                    });
+                    if constexpr (STORE_MID) {
+                        static_for<0, 4>([&](auto k_c) {
+                            SRHIP_CAPTURE(midv);
+                            buffer_store_b128_guarded(midv[decltype(k_c)::value], mid_srd, mvo[decltype(k_c)::value], mid_soff);
+                        });
+                    }
+                    lds_wait<0>();
+                }
+                return;
+            }
+
+            const unsigned dma_soff = row_soff(s + P::LA);
+            const unsigned dma_slot = (unsigned)((xpos == 0 ? P::RING - 1 : xpos - 1) * P::SLOT_BYTES);
+            unsigned rowa[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sl = xpos + ky;
+                rowa[ky] = lds_base + (unsigned)((sl >= P::RING ? sl - P::RING : sl) * P::SLOT_BYTES);
+            }
+            xpos = (xpos + 1 == P::RING) ? 0 : xpos + 1;
+
+            if constexpr (PAR == 0) {
+                if (s == 0) {  // first row of the item: nobody fetched its tap 0 yet
+                    static_for<0, P::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[0][kc] = lds_read_b128((rowa[0] + rd[0]) ^ (unsigned)(kc << 5));
+                    });
+                    lds_wait<0>();
+                    static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
+                }
+            }
+
+            static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(midv); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
+                SRHIP_CAPTURE(e_p0); SRHIP_CAPTURE(e_p1); SRHIP_CAPTURE(e_addr);
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                lds_wait<0>();  // this tap's fragments (issued during the previous tap) have landed
+                static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+                static_for<0, P::MPT>([&](auto m_c) {
+                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(midv); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
+                    SRHIP_CAPTURE(e_p0); SRHIP_CAPTURE(e_p1); SRHIP_CAPTURE(e_addr);
+                    constexpr int ml = decltype(m_c)::value;
+                    constexpr int kc = ml / P::NCT, ct = ml % P::NCT;
+                    constexpr int f = (t * P::KC + kc) * P::NCT + ct;
+                    mfma_vacc<(f < P::NFA1), (t == 0 && kc == 0)>(acc[PAR][ct], wreg[t][kc][ct], bq[cur][kc], biasv[ct]);
+                    // gaps 1..KC: pixel fragments of the next tap (tap 8: tap 0 of the next row, whose x rows are resident)
+                    if constexpr (ml >= 1 && ml <= P::KC) {
+                        constexpr int kr = ml - 1;
+                        bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3]) ^ (unsigned)(kr << 5));
+                    }
+                    // taps 0..7: quad t of the previous row's accumulators -> mid ring
+                    if constexpr (t < 8) {
+                        constexpr int qct = t / 4, qg = t % 4;
+                        if constexpr (ml == 0) e_p0 = pack_bf16x2(acc[PAR ^ 1][qct][4 * qg + 0], acc[PAR ^ 1][qct][4 * qg + 1]);
+                        if constexpr (ml == 1) e_p1 = pack_bf16x2(acc[PAR ^ 1][qct][4 * qg + 2], acc[PAR ^ 1][qct][4 * qg + 3]);
+                        if constexpr (ml == 2) e_p0 = relu_bf16x2(e_p0) & ymask;
+                        if constexpr (ml == 3) e_p1 = relu_bf16x2(e_p1) & ymask;
+                        if constexpr (ml == 5) e_addr = wyr ^ (unsigned)((4 * qct + qg) << 4);
+                        if constexpr (ml == 7) lds_write_b64(e_addr, e_p0, e_p1);
+                    }
+                    if constexpr (STORE_MID && t < 4 && ml == 5)
+                        buffer_store_b128_guarded(midv[t], mid_srd, mvo[t], mid_soff);
+                    if constexpr (t < P::MAXP && ml == 6) issue_piece(IntC<t + 0 * ml>{}, dma_soff, dma_slot);
+                    // tap 8: read the finished mid row (this wave's 32 pixels) back pixel-major for the store in the next step
+                    if constexpr (STORE_MID && t == 8 && ml >= 4) midv[ml - 4] = lds_read_u32x4(yslot + rb[ml - 4]);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
+                });
+            });
+            // MFMA result -> vector ALU readers of the next step: the hazard is invisible to the compiler inside asm
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[PAR][0]), "+v"(acc[PAR][1]));
+            // nothing stays in flight across the end of a step: next row's tap-0 fragments, the read-back, the mid writes
+            lds_wait<0>();
+            static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
+            if constexpr (STORE_MID) static_for<0, 4>([&](auto k_c) { SRHIP_CAPTURE(midv); SRHIP_LOAD_FENCE(midv[decltype(k_c)::value]); });
+        };
+
+        __builtin_amdgcn_s_barrier();  // every wave is done with the previous item's LDS rows
+#pragma unroll 1
+        for (int r = 0; r < P::LA; ++r) {
+            const unsigned so = row_soff(r);
+            static_for<0, P::MAXP>([&](auto m_c) { issue_piece(m_c, so, (unsigned)(r * P::SLOT_BYTES)); });
+        }
+        const int nsteps = nout + P::LAG;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += 2) {
+            step(IntC<0>{}, s);
+            if (s + 1 < nsteps) step(IntC<1>{}, s + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Waves 2-3: second layer.  Step s computes output row o = s - LAG (image row y0 + o) for the columns x0 + 32 pg + pl
+// from mid rows o .. o+2 of the ring; epilogue as in the single-layer kernel with the residual form.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_second_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
+                                                  const int lane)
+{
+    using P = PairCfg;
+    const int hl = lane >> 5, pl = lane & 31;
+    // vector-memory schedule of one row: tap t issues [store of group (t-2)/2 of the previous row: even t >= 2]
+    // [residual load t of this row: t < 4]; 8 operations, the last residual load is followed by 3 stores.
+    constexpr int NRES = P::NST;
+    constexpr int RES_WAIT = 3;
+
+    bf16x8 wreg[9][P::KC][P::NCT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kc = 0; kc < P::KC; ++kc)
+#pragma unroll
+            for (int ct = 0; ct < P::NCT; ++ct) wreg[t][kc][ct] = p.wpack2[((t * P::KC + kc) * P::NCT + ct) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<0, 9 * P::KC * P::NCT>([&](auto f_c) {   // the loads land before the row loop: see the first layer
+        SRHIP_CAPTURE(wreg);
+        constexpr int f = decltype(f_c)::value;
+        if constexpr (f < P::NFA2) asm volatile("" : "+a"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+        else asm volatile("" : "+v"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+    });
+    // store-time lane roles: lane = (pixel st_q of a group of 8 pixels, 8-channel chunk st_c)
+    const int st_q = lane / P::LPP, st_c = lane % P::LPP;
+    const int st_fw = pl & 15;
+    const unsigned stage_lds = lds_base + (unsigned)P::STAGE_OFF + (unsigned)(pg * P::STAGE_BYTES);
+    const unsigned wst = stage_lds + (unsigned)(pl * P::PXS) + (unsigned)(((hl ^ st_fw) & (P::NSLOT - 1)) << 4);
+    unsigned rdst[P::NST];
+#pragma unroll
+    for (int k = 0; k < P::NST; ++k) {
+        const int qq = k * P::PPI + st_q;
+        rdst[k] = stage_lds + (unsigned)(qq * P::PXS) + (unsigned)((((2 * st_c) ^ (qq & 15)) & (P::NSLOT - 1)) << 4);
+    }
+    float breg[8];  // alpha * bias of this lane's 8 store-time channels
+#pragma unroll
+    for (int r = 0; r < 8; ++r) breg[r] = (p.bias2 != nullptr ? p.bias2[st_c * 8 + r] : 0.0f) * p.alpha;
+    unsigned rd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = 32 * pg + pl + kx;
+        rd[kx] = (unsigned)(px * 128 + ((hl ^ ((px >> 1) & 7)) << 4));
+    }
+
+    const int H = p.h, W = p.w;
+    bf16x8 bq[2][P::KC];
+    f32x16 acc[P::NCT];
+    u32x4 resv[2][NRES];
+    f32x4 e_lo[2], e_hi[2];
+    float ev[8];
+
+    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+        const PairItem it = pair_decode_item(p, item);
+        const int x0 = it.x0, y0 = it.y0, nout = it.nout;
+        const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
+        const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
+        const i32x4 dst_srd = make_srd(p.dst + (long long)it.n * img, img);
+        const i32x4 res_srd = make_srd(p.src + (long long)it.n * img, img);
+        unsigned vox[P::NST];
+#pragma unroll
+        for (int k = 0; k < P::NST; ++k) {
+            const int jq = 32 * pg + k * P::PPI + st_q;   // output column within the strip
+            const int xq = x0 + jq;
+            vox[k] = (jq < P::TWO && xq < W) ? (unsigned)((xq * P::CH + st_c * 8) * 2) : kOobOffset;
+        }
+
+        auto epi_read = [&](auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            e_lo[k & 1] = lds_read_f32x4(rdst[k]);
+            e_hi[k & 1] = lds_read_f32x4(rdst[k] ^ 16u);
+        };
+        auto epi_elem = [&](auto k_c, auto e_c, auto ap_c) {
+            constexpr int k = decltype(k_c)::value;
+            constexpr int e = decltype(e_c)::value;
+            constexpr int AP = decltype(ap_c)::value;
+            const float x = e < 4 ? e_lo[k & 1][e & 3] : e_hi[k & 1][e & 3];
+            const float t = fmaf(x, p.alpha, breg[e]);
+            const unsigned rr = resv[AP][k][e >> 1];
+            const float rv = (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
+            ev[e] = fmaxf(t, t * p.slope2) + rv;
+        };
+        auto epi_store = [&](auto k_c, const unsigned store_soff) {
+            constexpr int k = decltype(k_c)::value;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
+            buffer_store_b128_guarded(o, dst_srd, vox[k], store_soff);
+        };
+
+        // One output row.  PAR = o & 1 selects the fragment buffer that holds tap 0 and the residual set.
+        auto row_body = [&](auto par_c, const int o) {
+            constexpr int PAR = decltype(par_c)::value;
+            const int y = y0 + o;
+            const unsigned res_soff = (unsigned)y * row_pitch;
+            const unsigned st_soff = o > 0 ? (unsigned)(y - 1) * row_pitch : kOobOffset;
+            unsigned rowa[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                rowa[ky] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(((o + ky) & (P::NY - 1)) * P::SLOT_BYTES);
+
+            if constexpr (PAR == 0) {
+                if (o == 0) {
+                    static_for<0, P::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[0][kc] = lds_read_b128((rowa[0] + rd[0]) ^ (unsigned)(kc << 5));
+                    });
+                    lds_wait<0>();
+                    static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
+                }
+            }
+
+            static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                constexpr int KG = (t - 1) / 2;                 // store group served by taps 2k+1, 2k+2
+                constexpr bool EPI = t >= 1 && KG < P::NST;
+                lds_wait<0>();
+                if constexpr (EPI && (t & 1)) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
+                static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+
+                constexpr int ESTEPS = !EPI ? 0 : ((t & 1) ? 4 : 5);
+                constexpr int NS = ESTEPS + (t < NRES ? 1 : 0);
+                static_for<0, P::MPT>([&](auto m_c) {
+                    SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
+                    SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                    constexpr int ml = decltype(m_c)::value;
+                    constexpr int kc = ml / P::NCT, ct = ml % P::NCT;
+                    constexpr int f = (t * P::KC + kc) * P::NCT + ct;
+                    mfma_pinned<(f < P::NFA2), (t == 0 && kc == 0), ct>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
+                    if constexpr (ml == 0 && (t % 2 == 0) && (t / 2 < P::NST)) epi_read(IntC<t / 2 + 0 * ml>{});
+                    if constexpr (ml >= 1 && ml <= P::KC) {
+                        constexpr int kr = ml - 1;
+                        bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3]) ^ (unsigned)(kr << 5));
+                    }
+                    static_for<ml * NS / P::MPT, (ml + 1) * NS / P::MPT>([&](auto s_c) {
+                        SRHIP_CAPTURE(resv); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                        constexpr int S = decltype(s_c)::value;
+                        if constexpr (S < ESTEPS) {
+                            constexpr int KD = KG + 0 * S;
+                            if constexpr (t & 1) {
+                                epi_elem(IntC<KD>{}, IntC<S + 0 * KD>{}, IntC<PAR ^ 1>{});
+                            } else {
+                                if constexpr (S < 4) epi_elem(IntC<KD>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
+                                else epi_store(IntC<KD>{}, st_soff);
+                            }
+                        } else {
+                            constexpr int TR = t + 0 * S;
+                            resv[PAR][TR] = buffer_load_b128_async(res_srd, vox[TR], res_soff);
+                        }
+                    });
+                    if constexpr (NS > 0) __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+
+            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]), "+" SRHIP_ACC_REG1(acc[1]));
+            static_for<0, 4 * P::NCT>([&](auto s_c) {
+                constexpr int S = decltype(s_c)::value;
+                constexpr int ct = S / 4, g = S % 4;
+                lds_write_acc_quad<ct, g>(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);
+            });
+            lds_wait<4 * P::NCT>();
+            static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
+            vm_wait<RES_WAIT>();
+            static_for<0, NRES>([&](auto k_c) { SRHIP_CAPTURE(resv); SRHIP_LOAD_FENCE(resv[PAR][decltype(k_c)::value]); });
+        };
+
+        __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
+        const int nsteps = nout + P::LAG;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += 2) {
+            // step s: output row s - LAG (LAG is even: the row parity is the step parity)
+            __builtin_amdgcn_s_barrier();
+            if (s >= P::LAG) row_body(IntC<0>{}, s - P::LAG);
+            if (s + 1 < nsteps) {
+                __builtin_amdgcn_s_barrier();
+                if (s + 1 >= P::LAG) row_body(IntC<1>{}, s + 1 - P::LAG);
+            }
+        }
+        // drain: second epilogue half of the last row
+        {
+            const unsigned st_soff = (unsigned)(y0 + nout - 1) * row_pitch;
+            auto tail = [&](auto ap_c) {
+                static_for<0, P::NST>([&](auto k_c) {
+                    SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                    epi_read(k_c);
+                    lds_wait<0>();
+                    SRHIP_LOAD_FENCE(e_lo[decltype(k_c)::value & 1]);
+                    SRHIP_LOAD_FENCE(e_hi[decltype(k_c)::value & 1]);
+                    static_for<0, 8>([&](auto e_c) { epi_elem(k_c, e_c, ap_c); });
+                    epi_store(k_c, st_soff);
+                });
+            };
+            if ((nout - 1) & 1) tail(IntC<1>{});
+            else tail(IntC<0>{});
+        }
+    }
+}
+
+template <bool STORE_MID>
+__global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    if (wave < 2) pair_first_layer<STORE_MID>(p, smem, lds_base, wave, lane);
+    else pair_second_layer(p, smem, lds_base, wave - 2, lane);
+}
+
+template <bool STORE_MID>
+int launch_pair(PairParams p, hipStream_t stream)
+{
+    using P = PairCfg;
+    static std::atomic<bool> configured_dev[kSrhipMaxDevices];  // per device
+    const int dev = srhip_current_device();
+    if (!configured_dev[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                P::LDS_BYTES) != hipSuccess) {
+            srhip_set_error("conv3x3_pair: cannot raise the dynamic LDS limit to %d", P::LDS_BYTES);
+            return SRHIP_ERR_LAUNCH;
+        }
+        configured_dev[dev].store(true, std::memory_order_release);
+    }
+    // work items = images x vertical segments x 62-column strips, one workgroup per CU walking them; a segment of R
+    // rows costs R + 2 first-layer rows + LAG steps of pipeline fill + the look-ahead's fill latency
+    const int slots = srhip_num_cus();
+    const int nstrips = srhip_div_up(p.w, P::TWO);
+    int best_segs = 1;
+    double best_cost = 1e30;
+    for (int rounds = 1; rounds <= 32; ++rounds) {
+        int segs = (int)(((long long)rounds * slots) / ((long long)nstrips * p.n));
+        if (segs < 1) segs = 1;
+        if (segs > p.h) segs = p.h;
+        const int seg_h = srhip_div_up(p.h, segs);
+        segs = srhip_div_up(p.h, seg_h);
+        const long long items = (long long)segs * nstrips * p.n;
+        const int r = srhip_div_up(items, slots);
+        const double cost = (double)r * (seg_h + P::LAG + 4.0);
+        if (cost < best_cost) { best_cost = cost; best_segs = segs; }
+    }
+    p.seg_h = srhip_div_up(p.h, best_segs);
+    p.nsegs = srhip_div_up(p.h, p.seg_h);
+    p.nstrips = nstrips;
+    const long long total = (long long)p.nsegs * nstrips * p.n;
+    SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_pair: too many work items");
+    p.total_items = (int)total;
+    const int grid = (int)(total < slots ? total : slots);
+    hipLaunchKernelGGL(conv3x3_pair_kernel<STORE_MID>, dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
+    return srhip_check_launch("conv3x3_pair_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* a, void* stream)
+{
+    SRHIP_REQUIRE(a != nullptr, "conv3x3_pair: null args");
+    SRHIP_REQUIRE(a->src && a->wpack1 && a->wpack2 && a->dst, "conv3x3_pair: null src / wpack1 / wpack2 / dst");
+    SRHIP_REQUIRE(a->dst != a->src && a->mid != a->src && (a->mid == nullptr || a->mid != a->dst),
+                  "conv3x3_pair: src, mid and dst must be distinct tensors (neighbouring strips read src while others write dst)");
+    SRHIP_REQUIRE(a->n >= 1 && a->h >= 1 && a->w >= 1, "conv3x3_pair: empty tensor");
+    SRHIP_REQUIRE(a->act2 == SRHIP_ACT_NONE || a->act2 == SRHIP_ACT_RELU || a->act2 == SRHIP_ACT_LRELU, "conv3x3_pair: bad activation %d", a->act2);
+    SRHIP_REQUIRE(a->alpha > 0.0f, "conv3x3_pair: alpha must be positive");
+    SRHIP_REQUIRE((long long)a->h * a->w * 64 * 2 < (1ll << 31), "conv3x3_pair: image too large for 32-bit offsets");
+    PairParams p;
+    p.src = (const char*)a->src;
+    p.wpack1 = (const bf16x8*)a->wpack1;
+    p.bias1 = a->bias1;
+    p.wpack2 = (const bf16x8*)a->wpack2;
+    p.bias2 = a->bias2;
+    p.mid = (char*)a->mid;
+    p.dst = (char*)a->dst;
+    p.n = a->n; p.h = a->h; p.w = a->w;
+    p.slope2 = a->act2 == SRHIP_ACT_NONE ? 1.0f : (a->act2 == SRHIP_ACT_RELU ? 0.0f : a->slope2);
+    p.alpha = a->alpha;
+    if (a->mid != nullptr) return launch_pair<true>(p, (hipStream_t)stream);
+    return launch_pair<false>(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -8,7 +8,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import Conv3x3Args, check, lib
+from ._lib import Conv3x3Args, Conv3x3PairArgs, check, lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 RES_ADD, RES_MASK, RES_PRE = 0, 1, 2
@@ -138,6 +138,30 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
                     res_mode=res_mode, ca_stride=ca_stride, cout_w=cout_w)
     check(lib.srhip_conv3x3_fwd(a, _stream()))
     return out
+
+
+def conv3x3_pair(x: torch.Tensor, wpack1: torch.Tensor, bias1: Optional[torch.Tensor], wpack2: torch.Tensor,
+                 bias2: Optional[torch.Tensor], act2: int = ACT_NONE, slope2: float = 0.0, alpha: float = 1.0,
+                 keep_mid: bool = False, out: Optional[torch.Tensor] = None):
+    """alpha * act2(conv2(relu(conv1(x) + b1)) + b2) + x for a 64-channel NHWC bf16 map in ONE launch (the
+    intermediate map stays in LDS).  ``keep_mid=True`` also returns relu(conv1(x) + b1) (the backward pass needs it)."""
+    x = _req(x, torch.bfloat16, "x")
+    if x.dim() != 4 or x.shape[-1] != 64:
+        raise ValueError("conv3x3_pair: expected an (N,H,W,64) map")
+    n, h, w, _ = x.shape
+    if bias1 is not None:
+        bias1 = _req(bias1, torch.float32, "bias1")
+    if bias2 is not None:
+        bias2 = _req(bias2, torch.float32, "bias2")
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != torch.bfloat16 or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
+        raise ValueError("conv3x3_pair: out must be a contiguous bf16 tensor of x's shape, distinct from x")
+    mid = torch.empty_like(x) if keep_mid else None
+    a = Conv3x3PairArgs(src=x.data_ptr(), wpack1=wpack1.data_ptr(), bias1=_ptr(bias1), wpack2=wpack2.data_ptr(), bias2=_ptr(bias2),
+                        mid=_ptr(mid), dst=out.data_ptr(), n=n, h=h, w=w, act2=act2, slope2=slope2, alpha=alpha)
+    check(lib.srhip_conv3x3_pair_fwd(a, _stream()))
+    return (out, mid) if keep_mid else out
 
 
 _wgrad_ws = {}

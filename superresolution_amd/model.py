@@ -12,6 +12,7 @@ Inside, activations are NHWC bf16, every convolution is one launch of the MFMA k
 bias / ReLU / residual / 0.2-scale fused, and both channel concats are folded into the consumer
 convolution (no concat tensor is materialised).
 """
+import os
 from typing import Dict, List, Union
 
 import torch
@@ -80,6 +81,7 @@ class SuperSampler(nn.Module):
         self.buffer_channels = buffer_channels
         self._init_parameters()
         self._packs: Dict[str, tuple] = {}
+        self.use_pair_kernel = os.environ.get("SRHIP_NO_PAIR", "0") != "1"
 
     def _init_parameters(self) -> None:
         # same rule and same visiting order as core/models/model.py:120-132
@@ -126,6 +128,19 @@ class SuperSampler(nn.Module):
         return F_.conv3x3(x, wp, conv.bias.detach(), conv.out_channels, src_b=xb, res=res, act=act, alpha=alpha,
                           out_nchw_f32=out_nchw_f32)
 
+    def _pair(self, name: str, conv_a: nn.Conv2d, conv_b: nn.Conv2d, x: Tensor, act2: int, alpha: float,
+              keep_mid: bool = False):
+        """alpha * act2(conv_b(relu(conv_a(x)))) + x as one launch (the intermediate map stays in LDS);
+        SRHIP_NO_PAIR=1 in the environment runs the two single-layer launches instead (A/B timing)."""
+        ch = x.shape[-1]
+        if self.use_pair_kernel and ch == 64 and conv_a.out_channels == 64 and conv_b.out_channels == 64:
+            wa, wb = self._pack(name + "a", conv_a, ch, ch), self._pack(name + "b", conv_b, ch, ch)
+            return F_.conv3x3_pair(x, wa, conv_a.bias.detach(), wb, conv_b.bias.detach(), act2=act2, alpha=alpha,
+                                   keep_mid=keep_mid)
+        t = self._conv(name + "a", conv_a, x, ch)
+        out = self._conv(name + "b", conv_b, t, ch, res=x, act=act2, alpha=alpha)
+        return (out, t) if keep_mid else out
+
     # ------------------------------------------------------------------ forward
     def forward(self, batch: Dict[str, Union[Tensor, int]]):
         lr_frames = batch.pop("lr_frames")
@@ -158,15 +173,13 @@ class SuperSampler(nn.Module):
         blks = self.gbuffers_extractor.blks
         for i in range(0, len(blks), 2):
             g = self._conv(f"ge{i}", blks[i][0], g, cin)
-            t = self._conv(f"ge{i + 1}a", blks[i + 1][0][0], g, bf)
-            g = self._conv(f"ge{i + 1}b", blks[i + 1][1][0], t, bf, res=g)  # x + relu(conv(.))
+            g = self._pair(f"ge{i + 1}", blks[i + 1][0][0], blks[i + 1][1][0], g, F_.ACT_RELU, 1.0)  # x + relu(conv(relu(conv(x))))
             cin = bf
 
         # main: concat(up, g) -> conv_in -> 6 x {x + 0.2 * conv(relu(conv(x)))}  (model.py:82-95,169)
         x = self._conv("main_in", self.main.conv_in[0], up, fr, xb=g, cin_b=bf)
         for i, blk in enumerate(self.main.conv_main):
-            t = self._conv(f"m{i}a", blk.blks[0], x, self.SR_CH)
-            x = self._conv(f"m{i}b", blk.blks[2], t, self.SR_CH, res=x, act=F_.ACT_NONE, alpha=0.2)
+            x = self._pair(f"m{i}", blk.blks[0], blk.blks[2], x, F_.ACT_NONE, 0.2)
         # after_main on concat(up, x) (model.py:170), final_conv (model.py:111-115,172)
         x = self._conv("after", self.after_main[0], up, fr, xb=x, cin_b=self.SR_CH)
         x = self._conv("fin0", self.final_conv[0], x, self.SR_CH)

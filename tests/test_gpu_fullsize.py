@@ -35,6 +35,36 @@ def test_conv3x3_4k_crop_consistency_bit_exact(F_):
         assert torch.equal(crop[:, iy0:iy0 + (y1 - y0), ix0:ix0 + (x1 - x0)], full[:, y0:y1, x0:x1])
 
 
+@pytest.mark.parametrize("size", [(1, H, W), (16, 1024, 1024)])
+def test_conv3x3_pair_fullsize_crop_consistency_bit_exact(F_, size):
+    """The fused residual pair at 2160x3840 and at the training size: any interior window equals the same pair run on
+    that window plus a 2-pixel halo, bit for bit, whatever strip / segment / pipeline position computed it; two runs
+    agree bit for bit; the form that also writes the intermediate map gives the same output."""
+    n, h, w = size
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand(n, h, w, 64, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    w1 = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    w2 = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    b1 = torch.randn(64, device="cuda", generator=g) * 0.1
+    b2 = torch.randn(64, device="cuda", generator=g) * 0.1
+    wp1, wp2 = F_.conv3x3_pack_weights(w1, 64, 64), F_.conv3x3_pack_weights(w2, 64, 64)
+    full = F_.conv3x3_pair(x, wp1, b1, wp2, b2, act2=F_.ACT_NONE, alpha=0.2)
+    assert bool(torch.isfinite(full.float()).all())
+    assert torch.equal(full, F_.conv3x3_pair(x, wp1, b1, wp2, b2, act2=F_.ACT_NONE, alpha=0.2))
+    full_m, mid = F_.conv3x3_pair(x, wp1, b1, wp2, b2, act2=F_.ACT_NONE, alpha=0.2, keep_mid=True)
+    assert torch.equal(full, full_m)
+    ref_mid = F_.conv3x3(x, wp1, b1, 64, act=F_.ACT_RELU)
+    assert float((mid.float() - ref_mid.float()).abs().max()) <= 2.0 ** -7 * float(ref_mid.float().abs().max())
+    assert torch.equal(full, F_.conv3x3(mid, wp2, b2, 64, res=x, act=F_.ACT_NONE, alpha=0.2))
+    wins = [(h // 2 - 50, h // 2 + 50, w // 2 - 100, w // 2 + 200), (0, 40, 0, 200), (h - 60, h, w - 140, w), (500, 517, 100, 229)]
+    for img in sorted({0, n - 1}):
+        for (y0, y1, x0, x1) in wins:
+            ya, yb, xa, xb = max(y0 - 2, 0), min(y1 + 2, h), max(x0 - 2, 0), min(x1 + 2, w)
+            crop = F_.conv3x3_pair(x[img:img + 1, ya:yb, xa:xb].contiguous(), wp1, b1, wp2, b2, act2=F_.ACT_NONE, alpha=0.2)
+            iy0, ix0 = y0 - ya, x0 - xa
+            assert torch.equal(crop[:, iy0:iy0 + (y1 - y0), ix0:ix0 + (x1 - x0)], full[img:img + 1, y0:y1, x0:x1])
+
+
 def test_supersampler_4k_crop_consistency_and_determinism():
     """Whole network at 540x960 -> 2160x3840: deterministic, and an LR crop with a 16-pixel LR halo
     (64 HR pixels > the receptive field of 3 LR + 25 HR layers) reproduces the full frame in its interior."""

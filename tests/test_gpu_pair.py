@@ -1,0 +1,113 @@
+"""GPU parity of the fused residual-pair kernel (srhip_conv3x3_pair_fwd): SRResidualBlock (core/models/model.py:22-33)
+and Residual(ConvActivation, ConvActivation) (core/models/model.py:17-19,70-73) as ONE launch.
+
+Checked against (a) the CPU oracle's composition of the two layers with the intermediate map rounded to bf16 exactly
+where the kernels round it (tolerance 2e-2 on bf16 outputs, as for every convolution; the fp32-accumulate bar of 1e-3
+is checked on the intermediate map, which the kernel can write out), and (b) the two single-layer launches it replaces
+(the second layer is the same arithmetic; the first adds the bias in front of the products instead of behind them, so a
+rare element of the intermediate map may land on the neighbouring bf16 value)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F_():
+    from superresolution_amd import functional
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return functional
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+def _case(seed, n, h, w, scale=0.06):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, h, w, 64, generator=g) - 0.5).to(torch.bfloat16)
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) * scale).to(torch.bfloat16).float()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) * scale).to(torch.bfloat16).float()
+    b1 = (torch.randn(64, generator=g) * 0.1).to(torch.bfloat16).float()
+    b2 = (torch.randn(64, generator=g) * 0.1).to(torch.bfloat16).float()
+    return x, w1, b1, w2, b2
+
+
+def _oracle_pair(x, w1, b1, w2, b2, relu2, alpha):
+    """fp32 composition on the CPU oracle with the intermediate map rounded to bf16 (NCHW arrays)."""
+    from oracle import oracle as orc
+    xn = x.float().permute(0, 3, 1, 2).contiguous().numpy()
+    mid32 = np.maximum(orc.conv2d(xn, w1.numpy(), b1.numpy(), 1, 1), 0.0)
+    mid = _bf16_round(mid32)
+    t = orc.conv2d(mid, w2.numpy(), b2.numpy(), 1, 1)
+    if relu2:
+        t = np.maximum(t, 0.0)
+    return mid32, alpha * t + xn
+
+
+@pytest.mark.parametrize("shape", [(1, 20, 70), (2, 37, 130), (1, 64, 62), (1, 5, 3), (1, 3, 63), (1, 9, 125), (3, 1, 1)])
+@pytest.mark.parametrize("form", ["sr_block", "residual"])
+def test_pair_matches_oracle_and_two_launches(F_, shape, form):
+    n, h, w = shape
+    relu2, alpha = (False, 0.2) if form == "sr_block" else (True, 1.0)
+    x, w1, b1, w2, b2 = _case(100 * h + w + n, n, h, w)
+    xc = x.cuda()
+    wp1 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64)
+    wp2 = F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    act2 = F_.ACT_RELU if relu2 else F_.ACT_NONE
+    out, mid = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=act2, alpha=alpha, keep_mid=True)
+    out_nomid = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=act2, alpha=alpha)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_nomid), "the form that also writes the intermediate map must give the same output"
+    # (b) the two launches the kernel replaces
+    t = F_.conv3x3(xc, wp1, b1.cuda(), 64, act=F_.ACT_RELU)
+    ref2 = F_.conv3x3(t, wp2, b2.cuda(), 64, res=xc, act=act2, alpha=alpha)
+    dm = (mid.float() - t.float()).abs()
+    assert float(dm.max()) <= 2.0 ** -7 * max(1.0, float(t.float().abs().max())), "intermediate map differs by more than one bf16 step"
+    assert float((dm > 0).float().mean()) <= 0.02
+    assert float((out.float() - ref2.float()).abs().max()) <= 1e-2
+    # (a) the oracle: intermediate map at the fp32-accumulate bar, output at the bf16 bar
+    mid32, ref = _oracle_pair(x, w1, b1, w2, b2, relu2, alpha)
+    got_mid = mid.float().permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got_mid - mid32).max() <= 1e-3 + 2.0 ** -8 * np.abs(mid32).max()   # fp32 accumulate, then ONE bf16 rounding
+    got = out.float().permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-2
+
+
+def test_pair_second_layer_is_bit_equal_given_the_same_intermediate(F_):
+    """With the kernel's own intermediate map fed to the single-layer kernel, the outputs agree bit for bit: the second
+    stage is the same arithmetic in the same order."""
+    x, w1, b1, w2, b2 = _case(7, 2, 45, 200)
+    xc = x.cuda()
+    wp1, wp2 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64), F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    for act2, alpha in ((F_.ACT_NONE, 0.2), (F_.ACT_RELU, 1.0), (F_.ACT_LRELU, 0.5)):
+        out, mid = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=act2, slope2=0.05, alpha=alpha, keep_mid=True)
+        ref = F_.conv3x3(mid, wp2, b2.cuda(), 64, res=xc, act=act2, slope=0.05, alpha=alpha)
+        assert torch.equal(out, ref)
+
+
+def test_pair_zero_padding_of_the_intermediate_map(F_):
+    """The second convolution must see ZEROS outside the image, not the first layer evaluated on padding: with a large
+    first-layer bias the two differ by far more than the tolerance along every border."""
+    n, h, w = 1, 70, 190     # several strips and, with few rows per item, several segments
+    x, w1, b1, w2, b2 = _case(11, n, h, w)
+    b1 = b1 + 2.0
+    xc = x.cuda()
+    wp1, wp2 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64), F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    out = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=F_.ACT_NONE, alpha=0.2)
+    _, ref = _oracle_pair(x, w1, b1, w2, b2, False, 0.2)
+    got = out.float().permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got - ref).max() <= 4e-2    # values are ~10x larger here (bias 2.0): bf16 step of the output
+
+
+def test_pair_rejects_bad_arguments(F_):
+    from superresolution_amd._lib import SrhipError
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16, device="cuda")
+    wp = F_.conv3x3_pack_weights(torch.zeros(64, 64, 3, 3, device="cuda"), 64, 64)
+    with pytest.raises(ValueError):
+        F_.conv3x3_pair(x[..., :32].contiguous(), wp, None, wp, None)
+    with pytest.raises(ValueError):
+        F_.conv3x3_pair(x, wp, None, wp, None, out=x)
+    with pytest.raises(SrhipError):
+        F_.conv3x3_pair(x, wp, None, wp, None, alpha=0.0)
