@@ -52,7 +52,7 @@ struct PairCfg {
     static constexpr int NPIECE = SLOT_BYTES / 1024;   // 9 LDS-DMA pieces per x row
     static constexpr int MAXP = 5;                     // pieces per first-layer wave per row (wave w: w, w+2, ..., w+8)
     static constexpr int LA = 5;                       // x rows fetched ahead of the row being computed
-    static constexpr int RING = LA + 1;                // x row slots
+    static constexpr int RING = 8;                     // x row slots: rows s-2 (the second layer's residual) .. s+LA in step s
     static constexpr int NY = 4;                       // mid row slots
     static constexpr int LAG = 4;                      // the second layer computes output row s - LAG in step s
     static constexpr int XRING_BYTES = RING * SLOT_BYTES;
@@ -160,11 +160,14 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
         for (int r = 0; r < 16; ++r)
             biasv[ct][r] = p.bias1 != nullptr ? p.bias1[ct * 32 + 8 * (r >> 2) + 4 * hl + (r & 3)] : 0.0f;
 
-    unsigned rd[3];  // chunk hl of LDS pixel 32 pg + pl + kx; chunk pair kc of the same pixel at rd ^ (kc << 5)
+    // fragment of k-chunk kr for tap column kx: chunk 2 kr + hl of LDS pixel 32 pg + pl + kx (chunk c of pixel px sits at
+    // 16-byte slot c ^ ((px >> 1) & 7)); slot bases are multiples of 1 KiB, so one add per read forms the address
+    unsigned rd[3][P::KC];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int px = 32 * pg + pl + kx;
-        rd[kx] = (unsigned)(px * 128 + ((hl ^ ((px >> 1) & 7)) << 4));
+#pragma unroll
+        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
     }
     const int q = 32 * pg + pl;                                             // this lane's mid pixel in the row image
     const unsigned wy = (unsigned)(q * 128 + 8 * hl + (((q >> 1) & 7) << 4));  // its quad (ct, g) goes to wy ^ ((4 ct + g) << 4)
@@ -239,7 +242,6 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             o1 = relu_bf16x2(pack_bf16x2(a[4 * g + 2], a[4 * g + 3])) & ymask;
         };
 
-        int xpos = 0;  // ring slot of x row s
         auto step = [&](auto par_c, const int s) {
             constexpr int PAR = decltype(par_c)::value;
             const bool compute = s < nout + 2;
@@ -282,20 +284,16 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             }
 
             const unsigned dma_soff = row_soff(s + P::LA);
-            const unsigned dma_slot = (unsigned)((xpos == 0 ? P::RING - 1 : xpos - 1) * P::SLOT_BYTES);
+            const unsigned dma_slot = (unsigned)(((s + P::LA) & (P::RING - 1)) * P::SLOT_BYTES);
             unsigned rowa[3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int sl = xpos + ky;
-                rowa[ky] = lds_base + (unsigned)((sl >= P::RING ? sl - P::RING : sl) * P::SLOT_BYTES);
-            }
-            xpos = (xpos + 1 == P::RING) ? 0 : xpos + 1;
+            for (int ky = 0; ky < 3; ++ky) rowa[ky] = lds_base + (unsigned)(((s + ky) & (P::RING - 1)) * P::SLOT_BYTES);
 
             if constexpr (PAR == 0) {
                 if (s == 0) {  // first row of the item: nobody fetched its tap 0 yet
                     static_for<0, P::KC>([&](auto kc_c) {
                         constexpr int kc = decltype(kc_c)::value;
-                        bq[0][kc] = lds_read_b128((rowa[0] + rd[0]) ^ (unsigned)(kc << 5));
+                        bq[0][kc] = lds_read_b128(rowa[0] + rd[0][kc]);
                     });
                     lds_wait<0>();
                     static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
@@ -309,7 +307,10 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                 constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
                 constexpr int tn = (t + 1) % 9;
                 constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
-                lds_wait<0>();  // this tap's fragments (issued during the previous tap) have landed
+                // this tap's fragments (issued during the previous tap) have landed; the mid write issued BEHIND them may
+                // still be in flight (LDS operations of a wave complete in order)
+                if constexpr (t >= 1) lds_wait<1>();
+                else lds_wait<0>();
                 static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
                 static_for<0, P::MPT>([&](auto m_c) {
                     SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(midv); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
@@ -321,7 +322,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                     // gaps 1..KC: pixel fragments of the next tap (tap 8: tap 0 of the next row, whose x rows are resident)
                     if constexpr (ml >= 1 && ml <= P::KC) {
                         constexpr int kr = ml - 1;
-                        bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3]) ^ (unsigned)(kr << 5));
+                        bq[nxt][kr] = lds_read_b128(rowa[kyn] + rd[tn % 3][kr]);
                     }
                     // taps 0..7: quad t of the previous row's accumulators -> mid ring
                     if constexpr (t < 8) {
@@ -368,15 +369,17 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
 // Waves 2-3: second layer.  Step s computes output row o = s - LAG (image row y0 + o) for the columns x0 + 32 pg + pl
 // from mid rows o .. o+2 of the ring; epilogue as in the single-layer kernel with the residual form.
 // ------------------------------------------------------------------------------------------------------------------
+// ACT2: activation of the second layer known at compile time (0 none, 1 ReLU, 2 LeakyReLU): its epilogue is the wave's
+// critical vector-ALU work, and the common forms need fewer instructions than max(t, slope * t).
+template <int ACT2>
 __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
                                                   const int lane)
 {
     using P = PairCfg;
     const int hl = lane >> 5, pl = lane & 31;
-    // vector-memory schedule of one row: tap t issues [store of group (t-2)/2 of the previous row: even t >= 2]
-    // [residual load t of this row: t < 4]; 8 operations, the last residual load is followed by 3 stores.
+    // The residual (x at the output pixel) is still in the x ring: four pixel-major LDS reads per row replace a second
+    // trip to memory.  The only vector-memory operations of these waves are the output stores: nothing to wait for.
     constexpr int NRES = P::NST;
-    constexpr int RES_WAIT = 3;
 
     bf16x8 wreg[9][P::KC][P::NCT];
 #pragma unroll
@@ -407,11 +410,18 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
     float breg[8];  // alpha * bias of this lane's 8 store-time channels
 #pragma unroll
     for (int r = 0; r < 8; ++r) breg[r] = (p.bias2 != nullptr ? p.bias2[st_c * 8 + r] : 0.0f) * p.alpha;
-    unsigned rd[3];
+    unsigned rd[3][P::KC];  // as in the first layer
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int px = 32 * pg + pl + kx;
-        rd[kx] = (unsigned)(px * 128 + ((hl ^ ((px >> 1) & 7)) << 4));
+#pragma unroll
+        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+    }
+    unsigned rres[NRES];  // residual of store group k: x-ring pixel 2 + 32 pg + 8 k + st_q (output column + 2), chunk st_c
+#pragma unroll
+    for (int k = 0; k < NRES; ++k) {
+        const int px = 2 + 32 * pg + k * P::PPI + st_q;
+        rres[k] = (unsigned)(px * 128 + ((st_c ^ ((px >> 1) & 7)) << 4));
     }
 
     const int H = p.h, W = p.w;
@@ -427,7 +437,6 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
         const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
         const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
         const i32x4 dst_srd = make_srd(p.dst + (long long)it.n * img, img);
-        const i32x4 res_srd = make_srd(p.src + (long long)it.n * img, img);
         unsigned vox[P::NST];
 #pragma unroll
         for (int k = 0; k < P::NST; ++k) {
@@ -449,7 +458,9 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
             const float t = fmaf(x, p.alpha, breg[e]);
             const unsigned rr = resv[AP][k][e >> 1];
             const float rv = (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
-            ev[e] = fmaxf(t, t * p.slope2) + rv;
+            if constexpr (ACT2 == 0) ev[e] = t + rv;
+            else if constexpr (ACT2 == 1) ev[e] = fmaxf(t, 0.0f) + rv;
+            else ev[e] = fmaxf(t, t * p.slope2) + rv;
         };
         auto epi_store = [&](auto k_c, const unsigned store_soff) {
             constexpr int k = decltype(k_c)::value;
@@ -463,7 +474,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
         auto row_body = [&](auto par_c, const int o) {
             constexpr int PAR = decltype(par_c)::value;
             const int y = y0 + o;
-            const unsigned res_soff = (unsigned)y * row_pitch;
+            const unsigned xrow = lds_base + (unsigned)(((o + 2) & (P::RING - 1)) * P::SLOT_BYTES);  // x row of this output row
             const unsigned st_soff = o > 0 ? (unsigned)(y - 1) * row_pitch : kOobOffset;
             unsigned rowa[3];
 #pragma unroll
@@ -474,7 +485,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                 if (o == 0) {
                     static_for<0, P::KC>([&](auto kc_c) {
                         constexpr int kc = decltype(kc_c)::value;
-                        bq[0][kc] = lds_read_b128((rowa[0] + rd[0]) ^ (unsigned)(kc << 5));
+                        bq[0][kc] = lds_read_b128(rowa[0] + rd[0][kc]);
                     });
                     lds_wait<0>();
                     static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
@@ -492,10 +503,11 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                 constexpr bool EPI = t >= 1 && KG < P::NST;
                 lds_wait<0>();
                 if constexpr (EPI && (t & 1)) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
+                if constexpr (t >= 2 && t % 2 == 0 && t / 2 <= NRES) SRHIP_LOAD_FENCE(resv[PAR][t / 2 - 1]);   // read in gap 0 of the previous tap
                 static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
 
                 constexpr int ESTEPS = !EPI ? 0 : ((t & 1) ? 4 : 5);
-                constexpr int NS = ESTEPS + (t < NRES ? 1 : 0);
+                constexpr int NS = ESTEPS;
                 static_for<0, P::MPT>([&](auto m_c) {
                     SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
                     SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
@@ -503,10 +515,14 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                     constexpr int kc = ml / P::NCT, ct = ml % P::NCT;
                     constexpr int f = (t * P::KC + kc) * P::NCT + ct;
                     mfma_pinned<(f < P::NFA2), (t == 0 && kc == 0), ct>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
+                    // gap 0: staging read-back of a store group of the previous row (even taps) or one residual read of
+                    // this row (odd taps); gaps 1..KC: pixel fragments of the next tap.  Every LDS read is issued early
+                    // in its tap, so the wait at the top of the next tap finds it complete.
                     if constexpr (ml == 0 && (t % 2 == 0) && (t / 2 < P::NST)) epi_read(IntC<t / 2 + 0 * ml>{});
+                    if constexpr (ml == 0 && (t % 2 == 1) && (t / 2 < NRES)) resv[PAR][t / 2] = lds_read_u32x4(xrow + rres[t / 2]);
                     if constexpr (ml >= 1 && ml <= P::KC) {
                         constexpr int kr = ml - 1;
-                        bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3]) ^ (unsigned)(kr << 5));
+                        bq[nxt][kr] = lds_read_b128(rowa[kyn] + rd[tn % 3][kr]);
                     }
                     static_for<ml * NS / P::MPT, (ml + 1) * NS / P::MPT>([&](auto s_c) {
                         SRHIP_CAPTURE(resv); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
@@ -519,9 +535,6 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                                 if constexpr (S < 4) epi_elem(IntC<KD>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
                                 else epi_store(IntC<KD>{}, st_soff);
                             }
-                        } else {
-                            constexpr int TR = t + 0 * S;
-                            resv[PAR][TR] = buffer_load_b128_async(res_srd, vox[TR], res_soff);
                         }
                     });
                     if constexpr (NS > 0) __builtin_amdgcn_sched_barrier(0);
@@ -536,8 +549,6 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
             });
             lds_wait<4 * P::NCT>();
             static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
-            vm_wait<RES_WAIT>();
-            static_for<0, NRES>([&](auto k_c) { SRHIP_CAPTURE(resv); SRHIP_LOAD_FENCE(resv[PAR][decltype(k_c)::value]); });
         };
 
         __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
@@ -572,7 +583,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
     }
 }
 
-template <bool STORE_MID>
+template <bool STORE_MID, int ACT2>
 __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -581,17 +592,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     if (wave < 2) pair_first_layer<STORE_MID>(p, smem, lds_base, wave, lane);
-    else pair_second_layer(p, smem, lds_base, wave - 2, lane);
+    else pair_second_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
 }
 
-template <bool STORE_MID>
+template <bool STORE_MID, int ACT2>
 int launch_pair(PairParams p, hipStream_t stream)
 {
     using P = PairCfg;
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];  // per device
     const int dev = srhip_current_device();
     if (!configured_dev[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 P::LDS_BYTES) != hipSuccess) {
             srhip_set_error("conv3x3_pair: cannot raise the dynamic LDS limit to %d", P::LDS_BYTES);
             return SRHIP_ERR_LAUNCH;
@@ -622,7 +633,7 @@ int launch_pair(PairParams p, hipStream_t stream)
     SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_pair: too many work items");
     p.total_items = (int)total;
     const int grid = (int)(total < slots ? total : slots);
-    hipLaunchKernelGGL(conv3x3_pair_kernel<STORE_MID>, dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
     return srhip_check_launch("conv3x3_pair_kernel");
 }
 
@@ -651,8 +662,10 @@ SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* a, void* str
     p.n = a->n; p.h = a->h; p.w = a->w;
     p.slope2 = a->act2 == SRHIP_ACT_NONE ? 1.0f : (a->act2 == SRHIP_ACT_RELU ? 0.0f : a->slope2);
     p.alpha = a->alpha;
-    if (a->mid != nullptr) return launch_pair<true>(p, (hipStream_t)stream);
-    return launch_pair<false>(p, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0>(p, s) : launch_pair<false, 0>(p, s);
+    if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1>(p, s) : launch_pair<false, 1>(p, s);
+    return a->mid != nullptr ? launch_pair<true, 2>(p, s) : launch_pair<false, 2>(p, s);
 }
 
 }  // extern "C"
