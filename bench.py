@@ -109,6 +109,54 @@ def dominant_kernel_time_ms(run_once, hr_h, frames):
     return sum(ts) / len(ts), ts[len(ts) // 2], len(ts)
 
 
+def pair_kernel_time_ms(run_once, hr_h, frames):
+    """Average duration of one launch of the fused residual-pair kernel (64 -> 64 -> 64, the dominant kernel of the
+    inference pass: 9 launches = two thirds of a frame) as it runs inside the network, measured with events on the
+    stream the kernel is launched on: every such launch of `frames` extra forward passes is bracketed."""
+    from superresolution_amd import functional as F_
+    real = F_.conv3x3_pair
+    evs = []
+
+    def timed(x, *a, **kw):
+        if x.shape[1] != hr_h:
+            return real(x, *a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = real(x, *a, **kw)
+        e1.record()
+        evs.append((e0, e1))
+        return out
+
+    F_.conv3x3_pair = timed
+    try:
+        for _ in range(frames):
+            run_once()
+        torch.cuda.synchronize()
+    finally:
+        F_.conv3x3_pair = real
+    if not evs:
+        return None
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts) / len(ts), ts[len(ts) // 2], len(ts)
+
+
+def pair_roofline_block(hr_h, hr_w, avg_ms, med_ms, launches):
+    """Roofline of the fused pair kernel: 2 x 73,728 FLOP and 2 x 128 B (x in, dst out) per pixel = 576 FLOP/B, above
+    the machine balance of 2500 TFLOP/s / 8 TB/s = 312 FLOP/B, so the bf16 MFMA peak is the roofline that bounds it."""
+    px = float(hr_h * hr_w)
+    flop, nbytes = 2.0 * px * 64 * 64 * 9 * 2, px * 256.0
+    tflops = flop / (avg_ms * 1e-3) / 1e12
+    traffic = measured_traffic_bytes("r2_b_pair_pmc.csv", "conv3x3_pair_kernel<false, 0>")
+    return {"bound": "mfma", "kernel": f"conv3x3_pair_kernel<false,0> (conv 64->64 + bias + ReLU -> conv 64->64 + bias, x 0.2, + x @ {hr_h}x{hr_w}; "
+                                       "9 of the 16 HR launches per frame)",
+            "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r2_b_pair_pmc.csv)" if traffic is not None else None,
+            "avg_launch_ms": avg_ms, "median_launch_ms": med_ms, "launches_timed": launches,
+            "algorithmic_bytes_per_launch": nbytes, "algorithmic_flop_per_launch": flop,
+            "hbm_view": {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+
 def roofline_block(kernel, flop, nbytes, avg_ms, med_ms, launches, traffic):
     """Roofline of the dominant kernel from its event-timed average launch duration.  Bound: HBM
     (arithmetic intensity 288 FLOP/B < 312 FLOP/B machine balance); the MFMA view is kept beside it."""
@@ -123,16 +171,16 @@ def roofline_block(kernel, flop, nbytes, avg_ms, med_ms, launches, traffic):
                           "frac": tflops / BF16_MFMA_PEAK_TFLOPS}}
 
 
-def measured_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed counter passes (separate
+def measured_traffic_bytes(name="r1_g_conv64_pmc.csv", kernel="Cfg<4, 2, 1, false, 0>"):
+    """HBM bytes per launch of a kernel from the committed counter passes (separate
     FETCH_SIZE and WRITE_SIZE runs, KiB units; FETCH_SIZE doubled as gfx950 tallies the 128-byte
     requests of wide streaming reads at 64 bytes).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_g_conv64_pmc.csv")
+    path = os.path.join(ROOT, "profiles", name)
     try:
         vals = {}
         for line in open(path):
             parts = line.rstrip().rsplit(",", 3)
-            if len(parts) == 4 and "Cfg<4, 2, 1, false, 0>" in parts[0] and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if len(parts) == 4 and kernel in parts[0] and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[parts[1]] = float(parts[3])
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     except (OSError, KeyError, ValueError):
@@ -628,6 +676,7 @@ def main():
     del first
 
     # every rank takes part in the instrumented passes and in the training leg (gradient all-reduce)
+    pair_t = pair_kernel_time_ms(step, HR_H, 5) if model.use_pair_kernel else None
     k_avg_ms, k_med_ms, k_launches = dominant_kernel_time_ms(step, HR_H, 5)
     train = None
     if not args.no_train:
@@ -656,10 +705,15 @@ def main():
                        "tflop_per_frame": flop_frame / 1e12,
                        "net_tflops": flop_frame / 1e12 / (ms_per_step * 1e-3),
                        "net_frac_of_bf16_mfma_peak": flop_frame / 1e12 / (ms_per_step * 1e-3) / BF16_MFMA_PEAK_TFLOPS},
-            "roofline": roofline_block("conv3x3_kernel<Cfg<4,2,1,false,0>> (64->64 3x3 + bias + ReLU @ 2160x3840, "
-                                       "12 of the 25 HR launches per frame)", k_flop, 2.0 * HR_H * HR_W * 64 * 2,
-                                       k_avg_ms, k_med_ms, k_launches, measured_traffic_bytes()),
         }
+        single = roofline_block("conv3x3_kernel<Cfg<4,2,1,false,0>> (64->64 3x3 + bias + ReLU @ 2160x3840, "
+                                "3 of the 16 HR launches per frame)", k_flop, 2.0 * HR_H * HR_W * 64 * 2,
+                                k_avg_ms, k_med_ms, k_launches, measured_traffic_bytes())
+        if pair_t is not None:
+            res["roofline"] = pair_roofline_block(HR_H, HR_W, *pair_t)
+            res["roofline_single_layer"] = single
+        else:
+            res["roofline"] = single
         if train is not None:
             res["train"] = train   # second half of the metric: train crops/s at this GPU count (weak scaling)
         if not args.no_cpu_baseline and world == 1:

@@ -78,8 +78,10 @@ class _SuperSamplerFn(torch.autograd.Function):
         xs = [m._conv("main_in", m.main.conv_in[0], up, fr, xb=g, cin_b=bf)]
         ts = []
         for i, blk in enumerate(m.main.conv_main):
-            ts.append(m._conv(f"m{i}a", blk.blks[0], xs[-1], sr))
-            xs.append(m._conv(f"m{i}b", blk.blks[2], ts[-1], sr, res=xs[-1], act=F_.ACT_NONE, alpha=0.2))
+            # one launch per block; the intermediate map is written out as well (the backward needs it)
+            x_next, t = m._pair(f"m{i}", blk.blks[0], blk.blks[2], xs[-1], F_.ACT_NONE, 0.2, keep_mid=True)
+            ts.append(t)
+            xs.append(x_next)
         a = m._conv("after", m.after_main[0], up, fr, xb=xs[-1], cin_b=sr)
         c0 = m._conv("fin0", m.final_conv[0], a, sr)
         out = m._conv("fin2", m.final_conv[2], c0, sr, act=F_.ACT_NONE, out_nchw_f32=True)

@@ -39,11 +39,21 @@ VARIANTS = {
 }
 
 
-def build():
+def build(only=None, rev=None):
+    """only: names to build (default all).  rev: also build `rev_<rev>` from that git revision of the source (an older
+    version of the kernel for an A/B in one process)."""
     os.makedirs(OUT, exist_ok=True)
     src = open(os.path.join(CSRC, "conv3x3_pair.hip")).read()
-    for name, patches in VARIANTS.items():
+    todo = dict(VARIANTS)
+    if only:
+        todo = {k: v for k, v in todo.items() if k in only}
+    if rev:
+        old = subprocess.check_output(["git", "-C", ROOT, "show", f"{rev}:superresolution_amd/csrc/conv3x3_pair.hip"], text=True)
+        todo[f"rev_{rev}"] = old
+    for name, patches in todo.items():
         text = src
+        if isinstance(patches, str):
+            text, patches = patches, []
         for a, b in patches:
             if text.count(a) < 1:
                 raise SystemExit(f"variant {name}: pattern not found: {a[:60]!r}")
@@ -59,7 +69,7 @@ def build():
         os.remove(path)
 
 
-def run(rounds):
+def run(rounds, only=None):
     sys.path.insert(0, ROOT)
     import torch
     from superresolution_amd import functional as F_
@@ -73,7 +83,12 @@ def run(rounds):
     b2 = torch.randn(64, device=dev) * 0.1
     out = torch.empty_like(x)
     libs = {}
-    for name in VARIANTS:
+    names = sorted(f[len("libpair_"):-3] for f in os.listdir(OUT) if f.startswith("libpair_") and f.endswith(".so"))
+    names = [n for n in names if only is None or n in only]
+    if "base" in names:
+        names.remove("base")
+        names.insert(0, "base")
+    for name in names:
         so = os.path.join(OUT, f"libpair_{name}.so")
         if os.path.exists(so):
             lib = ctypes.CDLL(so)
@@ -101,7 +116,14 @@ def run(rounds):
 
 
 if __name__ == "__main__":
+    # build [--rev REV] [names...] | run [rounds] [names...]
     if sys.argv[1] == "build":
-        build()
+        args = sys.argv[2:]
+        rev = None
+        if args and args[0] == "--rev":
+            rev, args = args[1], args[2:]
+        build(only=args or None, rev=rev)
     else:
-        run(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+        args = sys.argv[2:]
+        rounds = int(args[0]) if args else 7
+        run(rounds, only=args[1:] or None)
