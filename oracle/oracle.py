@@ -338,71 +338,108 @@ def supersampler_forward(sd, lr_frames, hr_buffers, return_intermediates=False):
     return sr
 
 
-def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn):
+def bf16_round(a):
+    """Round an fp32 array to the nearest bf16 value (ties to even), returned as fp32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(np.shape(a))
+
+
+def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf16=False):
     """Forward (core/models/model.py:147-175) and the backward ATen's autograd performs for it
     (loss.backward(), core/trainer.py:160): returns (sr, grads) with grads keyed like the state
-    dict.  `dsr_fn(sr)` supplies dL/d(sr) (the loss itself is outside this restatement)."""
-    lr = _c(lr_frames[:, -1])
-    hb = _c(hr_buffers[:, -1])
+    dict.  `dsr_fn(sr)` supplies dL/d(sr) (the loss itself is outside this restatement).
+
+    The backward is written in the order the GPU path evaluates it (ReLU masks folded into the product that a
+    data-gradient launch writes, residual fan-in added there too), which in fp32 is the same arithmetic as autograd's
+    up to summation order; this mode is pinned to the reference's gradients.  ``emulate_bf16=True`` additionally rounds
+    to bf16 every tensor the GPU path STORES as bf16 -- inputs, packed weights, every activation and every activation
+    gradient, once per kernel output -- while accumulation, the network output and all parameter gradients stay fp32:
+    the GPU gradients are held to that mode at a tight tolerance."""
+    r = bf16_round if emulate_bf16 else (lambda a: a)
+    relu = lambda a: np.maximum(a, np.float32(0))
+    lr = r(_c(lr_frames[:, -1]))
+    hb = r(_c(hr_buffers[:, -1]))
     th, tw = hb.shape[-2:]
     grads = {}
+    W = {k: (r(v) if k.endswith(".weight") else v) for k, v in sd.items()}     # weights are rounded when packed
 
-    def fwd(x, key, act=1):
-        return conv2d(x, sd[key + ".weight"], sd[key + ".bias"], 1, 1, act=act)
+    def conv(x, key):          # pre-activation, fp32
+        return conv2d(x, W[key + ".weight"], W[key + ".bias"], 1, 1, act=0)
 
-    def bwd(x, y, dy, key, act=1, need_dx=True):
-        """x -> y = act(conv(x)); dy = dL/dy.  Accumulates parameter grads, returns dL/dx."""
-        dz = dy * (y > 0) if act == 1 else dy
-        dw, db = conv2d_bwd_weight(x, dz, sd[key + ".weight"].shape, padding=1)
-        grads[key + ".weight"] = dw
-        grads[key + ".bias"] = db
-        return conv2d_bwd_input(dz, sd[key + ".weight"], x.shape, padding=1) if need_dx else None
+    def wgrad(x, dz, key, scale=None):
+        dw, db = conv2d_bwd_weight(x, dz, W[key + ".weight"].shape, padding=1)
+        if scale is not None:
+            dw, db = np.float32(scale) * dw, np.float32(scale) * db
+        grads[key + ".weight"], grads[key + ".bias"] = dw, db
 
-    # ---- forward, keeping every activation
+    def dgrad(dz, key, x_shape):
+        return conv2d_bwd_input(dz, W[key + ".weight"], x_shape, padding=1)
+
+    # ---- forward, keeping every activation (each one kernel output, rounded once)
     f = [lr]
     for i in range(3):
-        f.append(fwd(f[-1], f"frame_extractor.blks.{i}.0"))
-    up = upsample_grid_bilinear(f[-1], th, tw)
+        f.append(r(relu(conv(f[-1], f"frame_extractor.blks.{i}.0"))))
+    up = r(upsample_grid_bilinear(f[-1], th, tw))
     gb, g = [], hb
     for i in range(3):
-        x = fwd(g, f"gbuffers_extractor.blks.{2 * i}.0")
-        t1 = fwd(x, f"gbuffers_extractor.blks.{2 * i + 1}.0.0")
-        t2 = fwd(t1, f"gbuffers_extractor.blks.{2 * i + 1}.1.0")
+        x = r(relu(conv(g, f"gbuffers_extractor.blks.{2 * i}.0")))
+        t1 = r(relu(conv(x, f"gbuffers_extractor.blks.{2 * i + 1}.0.0")))
+        t2 = r(relu(conv(t1, f"gbuffers_extractor.blks.{2 * i + 1}.1.0")))
         gb.append((g, x, t1, t2))
-        g = x + t2
+        g = r(x + t2)
     cat0 = np.concatenate((up, g), axis=1)
-    xs = [fwd(cat0, "main.conv_in.0")]
-    ts, us = [], []
+    xs = [r(relu(conv(cat0, "main.conv_in.0")))]
+    ts = []
     for i in range(6):
-        ts.append(fwd(xs[-1], f"main.conv_main.{i}.blks.0"))
-        us.append(fwd(ts[-1], f"main.conv_main.{i}.blks.2", act=0))
-        xs.append(np.float32(0.2) * us[-1] + xs[-1])
+        ts.append(r(relu(conv(xs[-1], f"main.conv_main.{i}.blks.0"))))
+        xs.append(r(np.float32(0.2) * conv(ts[-1], f"main.conv_main.{i}.blks.2") + xs[-1]))   # model.py:33, one epilogue
     cat1 = np.concatenate((up, xs[-1]), axis=1)
-    a = fwd(cat1, "after_main.0")
-    c0 = fwd(a, "final_conv.0")
-    sr = fwd(c0, "final_conv.2", act=0)
+    a = r(relu(conv(cat1, "after_main.0")))
+    c0 = r(relu(conv(a, "final_conv.0")))
+    sr = conv(c0, "final_conv.2")
 
-    # ---- backward
-    d = bwd(c0, sr, _c(dsr_fn(sr)), "final_conv.2", act=0)
-    d = bwd(a, c0, d, "final_conv.0")
-    d = bwd(cat1, a, d, "after_main.0")
+    # ---- backward; dz_* are gradients of pre-activations
     nf = up.shape[1]
-    dup, dx = d[:, :nf].copy(), d[:, nf:].copy()
+    dz = r(_c(dsr_fn(sr)))
+    wgrad(c0, dz, "final_conv.2")
+    dz = r(dgrad(dz, "final_conv.2", c0.shape) * (c0 > 0))
+    wgrad(a, dz, "final_conv.0")
+    dz = r(dgrad(dz, "final_conv.0", a.shape) * (a > 0))
+    wgrad(cat1, dz, "after_main.0")
+    d = dgrad(dz, "after_main.0", cat1.shape)
+    dup, dx = r(d[:, :nf]), r(d[:, nf:])
     for i in reversed(range(6)):
-        dt = bwd(ts[i], us[i], np.float32(0.2) * dx, f"main.conv_main.{i}.blks.2", act=0)
-        dx = dx + bwd(xs[i], ts[i], dt, f"main.conv_main.{i}.blks.0")
-    d = bwd(cat0, xs[0], dx, "main.conv_in.0")
-    dup += d[:, :nf]
-    dg = d[:, nf:].copy()
+        kb, ka = f"main.conv_main.{i}.blks.2", f"main.conv_main.{i}.blks.0"
+        wgrad(ts[i], dx, kb, scale=0.2)
+        g2 = r(np.float32(0.2) * dgrad(dx, kb, ts[i].shape) * (ts[i] > 0))
+        wgrad(xs[i], g2, ka)
+        dx = r(dgrad(g2, ka, xs[i].shape) + dx)
+    dz = dx * (xs[0] > 0)
+    wgrad(cat0, dz, "main.conv_in.0")
+    d = dgrad(dz, "main.conv_in.0", cat0.shape)
+    dup = r(d[:, :nf] + dup)
+    dg = r(d[:, nf:])
     for i in reversed(range(3)):
         prev, x, t1, t2 = gb[i]
-        dt1 = bwd(t1, t2, dg, f"gbuffers_extractor.blks.{2 * i + 1}.1.0")
-        dxb = dg + bwd(x, t1, dt1, f"gbuffers_extractor.blks.{2 * i + 1}.0.0")
-        dg = bwd(prev, x, dxb, f"gbuffers_extractor.blks.{2 * i}.0", need_dx=i > 0)
+        k0, ka, kb = (f"gbuffers_extractor.blks.{2 * i}.0", f"gbuffers_extractor.blks.{2 * i + 1}.0.0",
+                      f"gbuffers_extractor.blks.{2 * i + 1}.1.0")
+        dt2 = dg * (t2 > 0)
+        wgrad(t1, dt2, kb)
+        dt1 = r(dgrad(dt2, kb, t1.shape) * (t1 > 0))
+        wgrad(x, dt1, ka)
+        dzb = r(dgrad(dt1, ka, x.shape) + dg) * (x > 0)
+        wgrad(prev, dzb, k0)
+        if i > 0:
+            dg = r(dgrad(dzb, k0, prev.shape))
     grid = np.broadcast_to(np.transpose(make_coord(th, tw), (0, 2, 3, 1)), (lr.shape[0], th, tw, 2)).copy()
     d, _ = grid_sample_bwd(f[3], grid, dup, align_corners=False, need_dgrid=False)
+    dz = r(d * (f[3] > 0))
     for i in reversed(range(3)):
-        d = bwd(f[i], f[i + 1], d, f"frame_extractor.blks.{i}.0", need_dx=i > 0)
+        key = f"frame_extractor.blks.{i}.0"
+        wgrad(f[i], dz, key)
+        if i > 0:
+            dz = r(dgrad(dz, key, f[i].shape) * (f[i] > 0))
     return sr, grads
 
 

@@ -124,15 +124,49 @@ def test_reprfn_training_forward_backward_vs_reference():
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
         worst.append((float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300)), cos, name))
     by_name = {n: (e, c) for e, c, n in worst}
-    # The layers behind the last activation see no mask: they must agree to bf16 rounding.
+    # The layers behind the last activation see no mask: they must agree with the fp32 reference to bf16 rounding.
     for name in ("upsampler.conv.weight", "upsampler.conv.bias", "lr_conv.weight", "lr_conv.bias", "reprfb4.esa.conv4.weight"):
         assert by_name[name][0] <= 2e-2 and by_name[name][1] >= 0.9995, (name, by_name[name])
-    # Further back every LeakyReLU layer adds mask disagreements: where a pre-activation is within bf16 rounding of zero,
-    # the bf16 network and the fp32 reference pick different slopes (1 vs 0.05) for that pixel.  Measured: relative L2
-    # error 1 % behind the last block's ESA, growing by a few percent per activation layer to <= 21 %, cosine >= 0.978.
+    # Further back the fp32 reference and ANY network that stores bf16 activations drift apart (where a pre-activation is
+    # within bf16 rounding of zero the two pick different LeakyReLU slopes): this loose bound only guards against gross
+    # errors.  The real gradient check is the next test, against the oracle that rounds where the kernels round.
     worst.sort(reverse=True)
     assert worst[0][0] <= 0.28 and min(c for _, c, _ in worst) >= 0.97, worst[:5]
-    assert np.median([e for e, _, _ in worst]) <= 0.15
+
+
+def test_reprfn_training_gradients_match_the_bf16_storage_oracle():
+    """All parameter gradients against oracle/reprfn_emul.py in its bf16-storage mode (the CPU suite pins the same
+    code in fp32 mode to the reference's gradients): relative L2 error <= 2e-2 and cosine >= 0.999 for EVERY tensor.
+    What is left between the two is fp32 summation order inside the convolutions."""
+    from oracle import reprfn_emul as E
+    from superresolution_amd import RepRFN
+    m, z = _golden_model()
+    torch.manual_seed(21)
+    m_cpu = RepRFN(3, 3, 48, 4, deploy=False)
+    with torch.no_grad():
+        for _, p in m_cpu.named_parameters():
+            if p.requires_grad:
+                p.copy_(_bf(p))
+    x, r = torch.from_numpy(z["x"]), torch.from_numpy(z["r"])
+    y_ref, g_ref = E.forward_backward(m_cpu, x, r, emulate=True)
+    y = m(x.cuda())
+    assert float((y.detach().cpu() - y_ref).abs().max()) <= 4e-3      # a few bf16 steps of the last feature map
+    (y * r.cuda()).sum().backward()
+    params = dict(m.named_parameters())
+    bad, stats = [], []
+    for name in (str(n) for n in z["names"]):
+        got, ref = params[name].grad.detach().cpu().double().ravel(), g_ref[name].double().ravel()
+        if name.endswith("_branch.b0"):     # analytically zero
+            scale = float(g_ref[name[:-2] + "bias"].abs().max())
+            assert float(got.abs().max()) <= 1e-3 * scale, name
+            continue
+        rel = float((got - ref).norm() / (ref.norm() + 1e-300))
+        cos = float(got @ ref / (got.norm() * ref.norm() + 1e-300))
+        stats.append((rel, cos, name))
+        if rel > 2e-2 or cos < 0.999:
+            bad.append((name, rel, cos))
+    assert not bad, (len(bad), sorted(bad, key=lambda t: -t[1])[:8])
+    assert len(stats) == len(z["names"]) - 36
 
 
 def test_reprfn_training_step_reduces_loss_and_matches_infer():

@@ -125,3 +125,40 @@ def test_batched_reparameterisation_equals_the_per_block_rule():
     d = RepBlock(16, 16, "lrelu", deploy=True)
     k, b = merged_kernels_autograd([d])[0]
     assert k is d.rbr_reparam.weight and b is d.rbr_reparam.bias
+
+
+def test_training_oracle_fp32_mode_is_pinned_to_the_reference_gradients():
+    """oracle/reprfn_emul.py restates the training step the way the HIP path computes it (one merged 3x3 kernel per
+    RepBlock, conv + LeakyReLU chains, ESA).  In its fp32 mode it must give the reference's own training-form output
+    and the gradient of EVERY parameter (tests/golden/reprfn_train.npz, stored as fp16 of grad / max|grad|: 5e-4
+    resolution); its bf16-storage mode, which the GPU gradients are held to, is the same code with roundings added."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import reprfn_emul as E
+    from superresolution_amd import RepRFN
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reprfn_train.npz"))
+    torch.manual_seed(21)
+    m = RepRFN(3, 3, 48, 4, deploy=False)
+    with torch.no_grad():
+        for _, p in m.named_parameters():
+            if p.requires_grad:
+                p.copy_(p.to(torch.bfloat16).float())
+    x, r = torch.from_numpy(z["x"]), torch.from_numpy(z["r"])
+    y, g = E.forward_backward(m, x, r, emulate=False)
+    assert float((y - torch.from_numpy(z["y"])).abs().max()) <= 2e-6
+    checked = 0
+    for name in (str(n) for n in z["names"]):
+        ref = torch.from_numpy(z["g." + name].astype(np.float32)) * float(z["gscale." + name])
+        if name.endswith("_branch.b0"):   # analytically zero (the stencils sum to 0): fp32 cancellation noise on both sides
+            scale = float(z["gscale." + name[:-2] + "bias"])
+            assert float(g[name].abs().max()) <= 1e-3 * scale and float(ref.abs().max()) <= 1e-3 * scale, name
+            continue
+        a, b = g[name].double().ravel(), ref.double().ravel()
+        assert float((a - b).norm() / b.norm()) <= 1e-3, name
+        assert float((a - b).abs().max() / b.abs().max()) <= 1e-3, name
+        checked += 1
+    assert checked == len(z["names"]) - 36 and checked >= 228
+    # the bf16-storage mode stays a small perturbation of the forward pass
+    y16, _ = E.forward_backward(m, x, r, emulate=True)
+    assert float((y16 - y).abs().max()) <= 2e-2
