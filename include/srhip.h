@@ -38,6 +38,7 @@ typedef enum {
 typedef enum { SRHIP_ACT_NONE = 0, SRHIP_ACT_RELU = 1, SRHIP_ACT_LRELU = 2 } srhip_act;
 typedef enum { SRHIP_BILINEAR = 0, SRHIP_NEAREST = 1 } srhip_interp;
 typedef enum { SRHIP_RES_ADD = 0, SRHIP_RES_MASK = 1, SRHIP_RES_PRE = 2 } srhip_res_mode;
+typedef enum { SRHIP_AUX_NONE = 0, SRHIP_AUX_EMIT = 1, SRHIP_AUX_MASKBITS = 2, SRHIP_AUX_DUALBITS = 3 } srhip_aux_mode;
 
 SRHIP_API int srhip_version(void);
 SRHIP_API const char* srhip_last_error(void);
@@ -94,7 +95,20 @@ typedef struct {
                             channel slice [src_a, src_a + ca) of every pixel of a wider NHWC tensor (single source) */
     int cout_w;          /* 0, or channels written per pixel (cout <= cout_w <= min(64, cout_stride), multiple of 8):
                             dst / res point at a channel slice of a wider NHWC tensor with cout_stride channels */
+    /* Sign bits of a ReLU output, 1 bit per element instead of a bf16 tensor, for the backward pass of
+     * core/models/model.py:17-19,61-79 under core/trainer.py:160 (64-channel layers; res_mode ADD or no residual):
+     *   aux: (N, H, ceil(W/32), 64) uint32, srhip_conv3x3_signbits_bytes() bytes.  For pixel x and channel c the bit is
+     *        word (x/32)*64 + (x%8)*8 + c/8, bit ((x%32)/8)*8 + c%8.
+     *   SRHIP_AUX_EMIT:     also WRITE the bits of X = alpha*act(conv+bias) > 0 (before `res` is added)
+     *   SRHIP_AUX_MASKBITS: dst = (X + res) where the bit is set, 0 elsewhere          (ReLU backward on a residual sum)
+     *   SRHIP_AUX_DUALBITS: dst = X; dst2 = X where the bit is set, 0 elsewhere        (a gradient and its masked copy) */
+    void* aux;
+    int aux_mode;        /* srhip_aux_mode */
+    void* dst2;          /* SRHIP_AUX_DUALBITS: (N,H,W,64) bf16 */
 } srhip_conv3x3_args;
+
+/* Bytes of the sign-bit tensor of an (n, h, w, 64) map. */
+SRHIP_API size_t srhip_conv3x3_signbits_bytes(int n, int h, int w);
 
 /* Bytes of the packed-weight buffer for a (ca+cb) -> cout 3x3 layer. */
 SRHIP_API size_t srhip_conv3x3_packed_bytes(int cin_padded, int cout);

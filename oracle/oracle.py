@@ -345,7 +345,7 @@ def bf16_round(a):
     return r.view(np.float32).reshape(np.shape(a))
 
 
-def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf16=False):
+def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf16=False, trace=None):
     """Forward (core/models/model.py:147-175) and the backward ATen's autograd performs for it
     (loss.backward(), core/trainer.py:160): returns (sr, grads) with grads keyed like the state
     dict.  `dsr_fn(sr)` supplies dL/d(sr) (the loss itself is outside this restatement).
@@ -385,8 +385,8 @@ def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf1
     for i in range(3):
         x = r(relu(conv(g, f"gbuffers_extractor.blks.{2 * i}.0")))
         t1 = r(relu(conv(x, f"gbuffers_extractor.blks.{2 * i + 1}.0.0")))
-        t2 = r(relu(conv(t1, f"gbuffers_extractor.blks.{2 * i + 1}.1.0")))
-        gb.append((g, x, t1, t2))
+        t2 = relu(conv(t1, f"gbuffers_extractor.blks.{2 * i + 1}.1.0"))     # never stored: the layer's epilogue adds x and
+        gb.append((g, x, t1, t2))                                            # keeps only the sign pattern of t2
         g = r(x + t2)
     cat0 = np.concatenate((up, g), axis=1)
     xs = [r(relu(conv(cat0, "main.conv_in.0")))]
@@ -435,6 +435,8 @@ def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf1
     grid = np.broadcast_to(np.transpose(make_coord(th, tw), (0, 2, 3, 1)), (lr.shape[0], th, tw, 2)).copy()
     d, _ = grid_sample_bwd(f[3], grid, dup, align_corners=False, need_dgrid=False)
     dz = r(d * (f[3] > 0))
+    if trace is not None:      # intermediate maps for debugging a mismatch (NCHW)
+        trace.update(up=up, g=g, x0=xs[0], x6=xs[-1], a=a, c0=c0, f3=f[3], dup=dup, dz_fe=dz)
     for i in reversed(range(3)):
         key = f"frame_extractor.blks.{i}.0"
         wgrad(f[i], dz, key)

@@ -43,6 +43,7 @@ class Conv3x3Args(ctypes.Structure):
         ("cout", c_int), ("cout_stride", c_int),
         ("act", c_int), ("slope", c_float), ("alpha", c_float),
         ("dst_nchw_f32", c_int), ("res_mode", c_int), ("ca_stride", c_int), ("cout_w", c_int),
+        ("aux", c_void_p), ("aux_mode", c_int), ("dst2", c_void_p),
     ]
 
 
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "srhip_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "srhip_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "srhip_conv3x3_packed_bytes": (c_size_t, [c_int, c_int]),
+    "srhip_conv3x3_signbits_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p]),
     "srhip_conv3x3_fwd": (c_int, [ctypes.POINTER(Conv3x3Args), c_void_p]),

@@ -46,6 +46,8 @@ struct ConvParams {
     int cout_w;     // channels this launch writes per pixel (<= cout_stride: a channel slice of a wider tensor)
     float slope, alpha;  // slope: 1 (no activation), 0 (ReLU) or the LeakyReLU slope
     float mask_slope;    // MASK epilogue: factor where the mask tensor is <= 0 (0: ReLU backward, s: LeakyReLU backward)
+    char* aux;           // sign-bit tensor (N, H, ceil(W/32), 64) uint32: written (EMIT) or read (MASKBITS / DUALBITS)
+    char* dst2;          // DUALBITS: second output, dst masked by the bits
     int nstrips, nsegs, seg_h, total_items;
 };
 
@@ -61,8 +63,16 @@ template <> struct SubLayout<3> { static constexpr int NSUB = 2; static constexp
 template <> struct SubLayout<4> { static constexpr int NSUB = 1; static constexpr int CS0 = 64, CS1 = 0; };
 template <> struct SubLayout<6> { static constexpr int NSUB = 2; static constexpr int CS0 = 32, CS1 = 64; };
 
-template <int KC_, int CT_TOTAL_, int CSPLIT_, bool OUT_F32_, int RES_>
+// AUX_: sign bits of an activation as ONE dword per lane and row (bit 8k + e = element e of the lane's store group k):
+//   1 EMIT      the epilogue also writes the bits of alpha * act(conv + bias) > 0 (before a residual is added)
+//   2 MASKBITS  the result (after the residual add, if any) is zeroed where its bit is clear
+//   3 DUALBITS  dst gets the result, dst2 the result zeroed where its bit is clear
+// Lane roles at store time are those of the NCT = 2, CSPLIT = 1 configurations (8 lanes per pixel, 4 store groups).
+template <int KC_, int CT_TOTAL_, int CSPLIT_, bool OUT_F32_, int RES_, int AUX_ = 0>
 struct Cfg {
+    static constexpr bool EMIT = AUX_ == 1, MASKBITS = AUX_ == 2, DUALBITS = AUX_ == 3;
+    static constexpr bool AUX_LOAD = MASKBITS || DUALBITS;
+    static_assert(AUX_ == 0 || (CT_TOTAL_ == 2 && CSPLIT_ == 1 && !OUT_F32_ && RES_ <= 1), "sign-bit forms: 64 output channels per wave, bf16 output");
     static constexpr bool OUT_F32 = OUT_F32_;   // epilogue writes fp32 NCHW instead of bf16 NHWC
     static constexpr bool HAS_RES = RES_ != 0;  // the epilogue reads a second tensor `res` (bf16 NHWC only):
     static constexpr bool RES_MASK = RES_ == 2; // 1: dst += res;  2: dst = res > 0 ? dst : 0 (ReLU backward)
@@ -110,10 +120,12 @@ struct Cfg {
     // one vector-memory operation of a kind per tap, placed in the late MFMA gaps of the tap (the early
     // gaps carry the LDS reads).  The fp32 NCHW form appends its 16*NCT stores after tap 8.
     static constexpr int clamp63(int v) { return v > 63 ? 63 : v; }  // vmcnt is a 6-bit field; smaller = safe
-    static constexpr int store_in_tap(int t) { return (!OUT_F32 && t >= 2 && t % 2 == 0 && (t - 2) / 2 < NST) ? 1 : 0; }
+    static constexpr int store_in_tap(int t) { return (!OUT_F32 && t >= 2 && t % 2 == 0 && (t - 2) / 2 < NST) ? (DUALBITS ? 2 : 1) : 0; }
     static constexpr int dma_in_tap(int t) { return t < MAXP ? 1 : 0; }
     static constexpr int res_in_tap(int t) { return t < NRES ? 1 : 0; }
-    static constexpr int vm_in_tap(int t) { return store_in_tap(t) + dma_in_tap(t) + res_in_tap(t); }
+    // sign bits: one dword load in tap 0 (behind the tap's other operations) or one dword store closing tap 8
+    static constexpr int aux_in_tap(int t) { return ((AUX_LOAD && t == 0) || (EMIT && t == 8)) ? 1 : 0; }
+    static constexpr int vm_in_tap(int t) { return store_in_tap(t) + dma_in_tap(t) + res_in_tap(t) + aux_in_tap(t); }
     static constexpr int vm_before_tap(int t) { int n = 0; for (int k = 0; k < t; ++k) n += vm_in_tap(k); return n; }
     static constexpr int VM_ROW = vm_before_tap(9) + (OUT_F32 ? 16 * NCT : 0);  // operations per iteration
     static constexpr int POS_LAST_DMA = vm_before_tap(MAXP - 1) + store_in_tap(MAXP - 1);
@@ -135,6 +147,9 @@ struct Cfg {
     // consumed by the epilogue micro-steps of iteration i+1 or by the drain after the loop: younger than its
     // last load is only the rest of its own iteration.
     static constexpr int res_wait() { return clamp63(VM_ROW - 1 - POS_LAST_RES); }
+    // the sign-bit load of a row is the last operation of its tap 0
+    static constexpr int POS_AUX_LOAD = vm_in_tap(0) - 1;
+    static constexpr int aux_wait() { return clamp63(VM_ROW - 1 - POS_AUX_LOAD); }
     static_assert(LA >= 4, "the wait-count formulas assume at least 4 rows of look-ahead");
     static_assert(MAXP <= 9 && NRES <= 9, "one LDS-DMA piece and one residual load per tap");
     static constexpr int NFRAG = 9 * KC * NCT;                      // weight fragments per wave
@@ -154,9 +169,9 @@ struct Cfg {
         if (t == 0 || OUT_F32) return 0;
         const int k = (t - 1) / 2;
         if (k >= NST) return 0;
-        return (t & 1) ? 4 : 5;
+        return (t & 1) ? 4 : 5 + (DUALBITS ? 1 : 0) + ((EMIT && t == 8) ? 1 : 0);
     }
-    static constexpr int tap_steps(int t) { return epi_steps(t) + dma_in_tap(t) + res_in_tap(t); }
+    static constexpr int tap_steps(int t) { return epi_steps(t) + dma_in_tap(t) + res_in_tap(t) + ((AUX_LOAD && t == 0) ? 1 : 0); }
 };
 
 template <class C>
@@ -238,6 +253,9 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
     // epilogue scratch carried between micro-steps
     f32x4 e_lo[2], e_hi[2];  // staging read-back of store group k lives in buffer k & 1
     float ev[8];
+    float ev2[8];            // DUALBITS: the masked copy
+    unsigned mbv[2] = {0u, 0u};  // sign bits of row i (loaded forms) live in mbv[i & 1]
+    unsigned mb_out = 0u;        // EMIT: bits of the row whose epilogue is running
 
     for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
         const int strip = item % p.nstrips;
@@ -263,6 +281,13 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)n * img_out, 0, (int)img_out, 0x00020000);
         const i32x4 dst_srd = make_srd(p.dst + (long long)n * img_out, img_out);
         const i32x4 res_srd = make_srd(C::HAS_RES ? p.res + (long long)n * img_out : p.dst, C::HAS_RES ? img_out : 0u);
+        // sign bits: one dword per lane, row and 32-pixel group; dst2 (DUALBITS) has dst's geometry
+        const int wgroups = (W + 31) >> 5;
+        const unsigned aux_pitch = (unsigned)wgroups * 256u;
+        const unsigned img_aux = (unsigned)H * aux_pitch;
+        const i32x4 aux_srd = make_srd(C::AUX_LOAD || C::EMIT ? p.aux + (long long)n * img_aux : p.dst, C::AUX_LOAD || C::EMIT ? img_aux : 0u);
+        const i32x4 dst2_srd = make_srd(C::DUALBITS ? p.dst2 + (long long)n * img_out : p.dst, C::DUALBITS ? img_out : 0u);
+        const unsigned aux_vo = (x0 + 32 * pg < W) ? (unsigned)((((x0 >> 5) + pg) * 64 + lane) * 4) : kOobOffset;
         const unsigned out_pitch = (unsigned)W * (unsigned)p.cout_stride * 2u;  // bytes per output row (NHWC)
         const int xpix = x0 + 32 * pg + pl;
 
@@ -333,6 +358,13 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 #pragma unroll
                 for (int k = 0; k < C::NRES; ++k) SRHIP_LOAD_FENCE(resv[AP][k]);
             }
+            if constexpr (C::AUX_LOAD) {
+                SRHIP_CAPTURE(mbv);
+                // the row's sign-bit dword was loaded in tap 0: older than the last residual load, so the wait above
+                // covers it where there is a residual
+                if constexpr (!C::HAS_RES) vm_wait<C::aux_wait()>();
+                SRHIP_LOAD_FENCE(mbv[AP]);
+            }
         };
         auto epi_read = [&](auto k_c) {  // staging reads of store group k (complete after the next LDS wait)
             constexpr int k = decltype(k_c)::value;
@@ -352,8 +384,19 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             }
             if constexpr (C::RES_PRE) t += rv;
             float v = fmaxf(t, t * p.slope);  // act(t) = max(t, slope * t), slope in {1, 0, s}
+            if constexpr (C::EMIT) {
+                // v > 0 as an integer test (a negative zero is not positive), deposited at bit 8k + e
+                const unsigned pos = __float_as_int(v) > 0 ? 1u : 0u;
+                mb_out = (k == 0 && e == 0) ? pos : (mb_out | (pos << (8 * k + e)));
+            }
             if constexpr (C::RES_MASK) v = rv > 0.0f ? v : v * p.mask_slope;
             else if constexpr (C::HAS_RES && !C::RES_PRE) v += rv;
+            if constexpr (C::AUX_LOAD) {
+                const unsigned keep = (unsigned)((int)(mbv[AP] << (31 - (8 * k + e))) >> 31);   // all ones where the bit is set
+                const float vm = __uint_as_float(__float_as_uint(v) & keep);
+                if constexpr (C::MASKBITS) v = vm;
+                else ev2[e] = vm;
+            }
             ev[e] = v;
         };
         auto epi_store = [&](auto k_c, const unsigned store_soff) {
@@ -362,6 +405,16 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
             buffer_store_b128_guarded(o, dst_srd, vox[k], store_soff);
+        };
+        auto epi_store2 = [&](auto k_c, const unsigned store_soff) {   // DUALBITS: the masked copy
+            constexpr int k = decltype(k_c)::value;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev2[2 * e], ev2[2 * e + 1]);
+            buffer_store_b128_guarded(o, dst2_srd, vox[k], store_soff);
+        };
+        auto emit_store = [&](const unsigned aux_soff) {               // EMIT: the finished row's sign bits
+            asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(mb_out), "v"(aux_vo), "s"(aux_srd), "s"(aux_soff) : "memory");
         };
 
         // One output row.  PAR = i & 1 selects the fragment buffer that holds tap 0 and the residual set.
@@ -386,6 +439,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             const unsigned dma_slot = (unsigned)((ring_pos == 0 ? C::RING - 1 : ring_pos - 1) * C::SLOT_BYTES);
             const unsigned res_soff = (unsigned)y * out_pitch;                       // residual of row i
             const unsigned st_soff = i > 0 ? (unsigned)(y - 1) * out_pitch : kOobOffset;  // stores of row i-1
+            const unsigned aux_ld_soff = (unsigned)y * aux_pitch;                    // sign bits of row i (loaded forms)
+            const unsigned aux_st_soff = i > 0 ? (unsigned)(y - 1) * aux_pitch : kOobOffset;  // ... of row i-1 (EMIT)
             unsigned rowa[3];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -410,6 +465,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
             // flight.  Between the MFMAs run this tap's micro-steps.
             static_for<0, 9>([&](auto t_c) {
                 SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                SRHIP_CAPTURE(mbv); SRHIP_CAPTURE(mb_out); SRHIP_CAPTURE(ev2); SRHIP_CAPTURE(aux_vo); SRHIP_CAPTURE(aux_srd); SRHIP_CAPTURE(aux_ld_soff);
                 constexpr int t = decltype(t_c)::value;
                 constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
                 constexpr int tn = (t + 1) % 9;                  // tap being fetched
@@ -433,6 +489,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                 constexpr int NS = C::tap_steps(t);
                 static_for<0, C::MPT>([&](auto m_c) {
                     SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc);
+                    SRHIP_CAPTURE(mbv); SRHIP_CAPTURE(mb_out); SRHIP_CAPTURE(ev2); SRHIP_CAPTURE(aux_vo); SRHIP_CAPTURE(aux_srd); SRHIP_CAPTURE(aux_ld_soff);
                     constexpr int ml = decltype(m_c)::value;
                     constexpr int kc = ml / C::NCT, ct = ml % C::NCT;
                     constexpr int f = (t * C::KC + kc) * C::NCT + ct;  // MFMA index within the row
@@ -448,7 +505,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                     }
                     // micro-steps [ml*NS/MPT, (ml+1)*NS/MPT) of this tap
                     static_for<ml * NS / C::MPT, (ml + 1) * NS / C::MPT>([&](auto s_c) {
-                        SRHIP_CAPTURE(resv);
+                        SRHIP_CAPTURE(resv); SRHIP_CAPTURE(mbv); SRHIP_CAPTURE(mb_out); SRHIP_CAPTURE(ev2); SRHIP_CAPTURE(aux_vo); SRHIP_CAPTURE(aux_srd); SRHIP_CAPTURE(aux_ld_soff);
                         constexpr int S = decltype(s_c)::value;
                         constexpr int E = C::epi_steps(t);
                         if constexpr (S < E) {
@@ -457,14 +514,18 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                                 epi_elem(IntC<KD>{}, IntC<S + 0 * KD>{}, IntC<PAR ^ 1>{});
                             } else {
                                 if constexpr (S < 4) epi_elem(IntC<KD>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
-                                else epi_store(IntC<KD>{}, st_soff);
+                                else if constexpr (S == 4) epi_store(IntC<KD>{}, st_soff);
+                                else if constexpr (C::DUALBITS) epi_store2(IntC<KD>{}, st_soff);   // S == 5
+                                else emit_store(aux_st_soff);                                   // S == 5, tap 8 (EMIT)
                             }
                         } else if constexpr (S < E + C::dma_in_tap(t)) {
                             constexpr int TD = t + 0 * S;  // dependent on S: the dead branch is not instantiated
                             issue_piece(IntC<TD>{}, dma_s0, dma_s1, dma_slot);
-                        } else {
+                        } else if constexpr (S < E + C::dma_in_tap(t) + C::res_in_tap(t)) {
                             constexpr int TR = t + 0 * S;
                             resv[PAR][TR] = buffer_load_b128_async(res_srd, vox[TR], res_soff);
+                        } else {   // tap 0 of the loaded sign-bit forms: this row's dword
+                            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(mbv[PAR]) : "v"(aux_vo), "s"(aux_srd), "s"(aux_ld_soff));
                         }
                     });
                     if constexpr (NS > 0) __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
@@ -536,7 +597,9 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                     SRHIP_LOAD_FENCE(e_hi[decltype(k_c)::value & 1]);
                     static_for<0, 8>([&](auto e_c) { epi_elem(k_c, e_c, ap_c); });
                     epi_store(k_c, st_soff);
+                    if constexpr (C::DUALBITS) epi_store2(k_c, st_soff);
                 });
+                if constexpr (C::EMIT) emit_store((unsigned)(y1 - 1) * aux_pitch);
             };
             if ((nout - 1) & 1) tail(IntC<1>{});
             else tail(IntC<0>{});
@@ -636,6 +699,12 @@ int launch_conv(ConvParams p, hipStream_t stream)
 
 extern "C" {
 
+SRHIP_API size_t srhip_conv3x3_signbits_bytes(int n, int h, int w)
+{
+    if (n < 1 || h < 1 || w < 1) return 0;
+    return (size_t)n * h * ((w + 31) / 32) * 256;
+}
+
 SRHIP_API size_t srhip_conv3x3_packed_bytes(int cin_padded, int cout)
 {
     const int kc = cin_padded / 16;
@@ -711,6 +780,26 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
     SRHIP_REQUIRE(a->alpha > 0.0f, "conv3x3: alpha must be positive");
     SRHIP_REQUIRE(a->res_mode == SRHIP_RES_ADD || a->res_mode == SRHIP_RES_MASK || a->res_mode == SRHIP_RES_PRE, "conv3x3: bad res_mode %d", a->res_mode);
     hipStream_t s = (hipStream_t)stream;
+    p.aux = (char*)a->aux;
+    p.dst2 = (char*)a->dst2;
+    if (a->aux_mode != SRHIP_AUX_NONE) {
+        SRHIP_REQUIRE(a->aux != nullptr, "conv3x3: aux_mode %d needs the sign-bit tensor `aux`", a->aux_mode);
+        SRHIP_REQUIRE(!a->dst_nchw_f32 && ct == 2 && a->cb == 0 && a->ca_stride == 0 && a->cout_w == 0 && a->cout_stride == 64,
+                      "conv3x3: the sign-bit forms take one source and write whole 64-channel bf16 maps");
+        SRHIP_REQUIRE(a->res == nullptr || a->res_mode == SRHIP_RES_ADD, "conv3x3: the sign-bit forms combine with the ADD residual only");
+        SRHIP_REQUIRE((long long)a->h * ((a->w + 31) / 32) * 256 < (1ll << 31), "conv3x3: sign-bit tensor too large for 32-bit offsets");
+        if (a->aux_mode == SRHIP_AUX_EMIT) {
+            if (kc == 4) return a->res ? launch_conv<Cfg<4, 2, 1, false, 1, 1>>(p, s) : launch_conv<Cfg<4, 2, 1, false, 0, 1>>(p, s);
+            if (kc == 1 && a->res == nullptr) return launch_conv<Cfg<1, 2, 1, false, 0, 1>>(p, s);
+        } else if (a->aux_mode == SRHIP_AUX_MASKBITS) {
+            if (kc == 4 && a->res != nullptr) return launch_conv<Cfg<4, 2, 1, false, 1, 2>>(p, s);
+        } else if (a->aux_mode == SRHIP_AUX_DUALBITS) {
+            SRHIP_REQUIRE(a->dst2 != nullptr && a->dst2 != a->dst, "conv3x3: the dual form needs a second output tensor `dst2`");
+            if (kc == 4 && a->res == nullptr) return launch_conv<Cfg<4, 2, 1, false, 0, 3>>(p, s);
+        }
+        srhip_set_error("conv3x3: sign-bit form %d is not built for cin=%d with%s residual", a->aux_mode, a->ca, a->res ? "" : "out");
+        return SRHIP_ERR_INVALID;
+    }
 #define SRHIP_CONV_CASE(KC, CT, CSPLIT)                                                                 \
     if (kc == KC && ct == CT) {                                                                         \
         if (a->dst_nchw_f32) return launch_conv<Cfg<KC, CT, CSPLIT, true, 0>>(p, s);                    \

@@ -12,6 +12,7 @@ from ._lib import Conv3x3Args, Conv3x3PairArgs, check, lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 RES_ADD, RES_MASK, RES_PRE = 0, 1, 2
+AUX_NONE, AUX_EMIT, AUX_MASKBITS, AUX_DUALBITS = 0, 1, 2, 3
 _MODES = {"bilinear": 0, "nearest": 1}
 
 
@@ -89,14 +90,19 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
             src_b: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, act: int = ACT_NONE,
             slope: float = 0.0, alpha: float = 1.0, out_nchw_f32: bool = False,
             cout_stride: Optional[int] = None, out: Optional[torch.Tensor] = None,
-            res_mode: int = RES_ADD, ca_slice: Optional[tuple] = None, out_off: Optional[int] = None) -> torch.Tensor:
+            res_mode: int = RES_ADD, ca_slice: Optional[tuple] = None, out_off: Optional[int] = None,
+            signbits: Optional[torch.Tensor] = None, aux_mode: int = AUX_NONE, out2: Optional[torch.Tensor] = None):
     """dst = alpha * act(conv3x3(concat(src_a, src_b)) + bias) + res   (NHWC bf16 activations);
     with ``res_mode=RES_MASK``: dst = alpha * act(...) * (res > 0 ? 1 : m), m = 0 or (act NONE) m = ``slope``;
     with ``res_mode=RES_PRE``: dst = act(alpha * (conv + bias) + res) (partial sums of layers wider than one launch).
 
     ``ca_slice=(off, n)``: read only channels [off, off+n) of src_a (n a multiple of 16, off of 8) - no copy.
     ``out_off=k`` (with ``out`` a wider NHWC tensor): write pad16(cout) channels at channel offset k of ``out``;
-    ``res`` (if given) is then a tensor of out's shape and is read at the same offset (it may be ``out`` itself)."""
+    ``res`` (if given) is then a tensor of out's shape and is read at the same offset (it may be ``out`` itself).
+
+    Sign-bit forms (64-channel layers; ``signbits`` from :func:`signbits_empty`), with X = alpha * act(conv + bias):
+    ``AUX_EMIT`` also writes the bits of X > 0 and returns (dst, signbits); ``AUX_MASKBITS`` returns (X + res) where the bit
+    is set and 0 elsewhere; ``AUX_DUALBITS`` returns (X, X where the bit is set and 0 elsewhere)."""
     src_a = _req(src_a, torch.bfloat16, "src_a")
     n, h, w, ca_full = src_a.shape
     a_ptr, ca, ca_stride = src_a.data_ptr(), ca_full, 0
@@ -136,8 +142,43 @@ def conv3x3(src_a: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tenso
                     res=None if res is None else res.data_ptr() + d_off, dst=out.data_ptr() + d_off, n=n, h=h, w=w, ca=ca, cb=cb,
                     cout=cout, cout_stride=cout_stride, act=act, slope=slope, alpha=alpha, dst_nchw_f32=int(out_nchw_f32),
                     res_mode=res_mode, ca_stride=ca_stride, cout_w=cout_w)
+    if aux_mode != AUX_NONE:
+        if aux_mode == AUX_EMIT and signbits is None:
+            signbits = signbits_empty(n, h, w, src_a.device)
+        if signbits is None or signbits.dtype != torch.int32 or not signbits.is_contiguous() or signbits.device != src_a.device \
+                or tuple(signbits.shape) != (n, h, (w + 31) // 32, 64):
+            raise ValueError("conv3x3: `signbits` must be the int32 tensor signbits_empty(n, h, w) gives")
+        a.aux, a.aux_mode = signbits.data_ptr(), aux_mode
+        if aux_mode == AUX_DUALBITS:
+            if out2 is None:
+                out2 = torch.empty_like(out)
+            if out2.dtype != torch.bfloat16 or not out2.is_contiguous() or out2.shape != out.shape or out2.device != out.device:
+                raise ValueError("conv3x3: `out2` must be a contiguous bf16 tensor of the output's shape")
+            a.dst2 = out2.data_ptr()
     check(lib.srhip_conv3x3_fwd(a, _stream()))
+    if aux_mode == AUX_EMIT:
+        return out, signbits
+    if aux_mode == AUX_DUALBITS:
+        return out, out2
     return out
+
+
+def signbits_empty(n: int, h: int, w: int, device) -> torch.Tensor:
+    """Uninitialised sign-bit tensor of an (n, h, w, 64) map: 1 bit per element, (n, h, ceil(w/32), 64) int32."""
+    t = torch.empty((n, h, (w + 31) // 32, 64), dtype=torch.int32, device=device)
+    assert t.numel() * 4 == lib.srhip_conv3x3_signbits_bytes(n, h, w)
+    return t
+
+
+def signbits_unpack(bits: torch.Tensor, w: int) -> torch.Tensor:
+    """(n, h, ceil(w/32), 64) int32 sign bits -> (n, h, w, 64) bool (torch ops; for tests and debugging).
+    Pixel x, channel c: word (x//32)*64 + (x%8)*8 + c//8, bit ((x%32)//8)*8 + c%8."""
+    n, h, g, _ = bits.shape
+    wd = bits.view(n, h, g, 8, 8)                              # [.., x%8, c//8]
+    sh = torch.arange(32, device=bits.device, dtype=torch.int32).view(4, 8)  # [(x%32)//8, c%8]
+    b = (wd[..., None, None] >> sh) & 1                        # n h g x8 c8 xq c%8
+    b = b.permute(0, 1, 2, 5, 3, 4, 6).reshape(n, h, g * 32, 64)
+    return b[:, :, :w].bool()
 
 
 def conv3x3_pair(x: torch.Tensor, wpack1: torch.Tensor, bias1: Optional[torch.Tensor], wpack2: torch.Tensor,

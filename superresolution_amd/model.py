@@ -110,23 +110,28 @@ class SuperSampler(nn.Module):
         return self._cached_pack(name, w, lambda: F_.conv3x3_pack_weights(w.detach(), cin_a, ca_pad, cin_b, cb_pad))
 
     def _dgrad(self, name: str, conv: nn.Conv2d, dz: Tensor, lo: int = 0, n: int = None, mask: Tensor = None,
-               res: Tensor = None, alpha: float = 1.0) -> Tensor:
+               res: Tensor = None, alpha: float = 1.0, signbits: Tensor = None, aux_mode: int = F_.AUX_NONE):
         """Gradient w.r.t. input channels [lo, lo+n) of ``conv`` from dz, the gradient of its pre-activation
         output: alpha * conv_transpose(dz), then either masked by a saved ReLU output (``mask``) or added to
-        ``res``.  Runs the forward kernel on transposed, flipped weights."""
+        ``res``.  Runs the forward kernel on transposed, flipped weights.  With ``signbits`` (the 1-bit-per-element
+        ReLU pattern a forward launch emitted): ``AUX_MASKBITS`` masks the sum with ``res``, ``AUX_DUALBITS`` returns
+        the gradient and its masked copy."""
         w = conv.weight
         n = conv.in_channels - lo if n is None else n
         wp = self._cached_pack(f"{name}^T{lo}", w, lambda: F_.conv3x3_pack_weights(
             w.detach(), conv.out_channels, dz.shape[-1], cout=n, cout_off=lo, transpose_flip=True))
+        if aux_mode != F_.AUX_NONE:
+            return F_.conv3x3(dz, wp, None, n, res=res, act=F_.ACT_NONE, alpha=alpha, signbits=signbits, aux_mode=aux_mode)
         second = mask if mask is not None else res
         return F_.conv3x3(dz, wp, None, n, res=second, act=F_.ACT_NONE, alpha=alpha,
                           res_mode=F_.RES_MASK if mask is not None else F_.RES_ADD)
 
     def _conv(self, name: str, conv: nn.Conv2d, x: Tensor, cin_a: int, xb: Tensor = None, cin_b: int = 0,
-              res: Tensor = None, act: int = F_.ACT_RELU, alpha: float = 1.0, out_nchw_f32: bool = False) -> Tensor:
+              res: Tensor = None, act: int = F_.ACT_RELU, alpha: float = 1.0, out_nchw_f32: bool = False,
+              aux_mode: int = F_.AUX_NONE):
         wp = self._pack(name, conv, cin_a, x.shape[-1], cin_b, 0 if xb is None else xb.shape[-1])
         return F_.conv3x3(x, wp, conv.bias.detach(), conv.out_channels, src_b=xb, res=res, act=act, alpha=alpha,
-                          out_nchw_f32=out_nchw_f32)
+                          out_nchw_f32=out_nchw_f32, aux_mode=aux_mode)
 
     def _pair(self, name: str, conv_a: nn.Conv2d, conv_b: nn.Conv2d, x: Tensor, act2: int, alpha: float,
               keep_mid: bool = False):

@@ -16,7 +16,7 @@ With autograd enabled the module runs `forward_train`: the same graph from diffe
 (`autograd_ops.py`), each RepBlock still ONE convolution whose merged kernel is differentiated back to the nine
 branches.
 """
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -219,21 +219,23 @@ class ESA(nn.Module):
         return F_.sigmoid_gate(x, c4)
 
 
-def _esa_train(esa: "ESA", x: Tensor) -> Tensor:
-    """ESA.run with differentiable operators (x: 64-channel padded feature map)."""
+def _esa_train(esa: "ESA", x: Tensor, rec=None) -> Tensor:
+    """ESA.run with differentiable operators (x: 64-channel padded feature map).  ``rec(name, tensor)`` records the
+    stored map of every operator (tests)."""
     from . import autograd_ops as A
+    rec = rec or (lambda name, t: t)
     cs = x.shape[-1]
-    c1_ = A.conv1x1(x, esa.conv1.weight, esa.conv1.bias)
+    c1_ = rec("c1_", A.conv1x1(x, esa.conv1.weight, esa.conv1.bias))
     # 3x3 / stride 2 / pad 0 = the stride-1 pad-1 layer at the odd pixels (2o + 1)
     full = A.conv3x3(c1_, esa.conv2.weight, esa.conv2.bias)
     ho, wo = (full.shape[1] - 3) // 2 + 1, (full.shape[2] - 3) // 2 + 1
-    c1 = full[:, 1:2 * ho:2, 1:2 * wo:2, :].contiguous()
-    v_max = A.max_pool2d(c1, 7, 3)
-    c3 = A.conv3x3(v_max, esa.conv3.weight, esa.conv3.bias)
-    cf = A.conv1x1(c1_, esa.conv_f.weight, esa.conv_f.bias)
-    s = A.resize_add(c3, cf)
-    c4 = A.conv1x1(s, esa.conv4.weight, esa.conv4.bias, cout_stride=cs)
-    return A.sigmoid_gate(x, c4)
+    c1 = rec("c1", full[:, 1:2 * ho:2, 1:2 * wo:2, :].contiguous())
+    v_max = rec("vmax", A.max_pool2d(c1, 7, 3))
+    c3 = rec("c3", A.conv3x3(v_max, esa.conv3.weight, esa.conv3.bias))
+    cf = rec("cf", A.conv1x1(c1_, esa.conv_f.weight, esa.conv_f.bias))
+    s = rec("s", A.resize_add(c3, cf))
+    c4 = rec("c4", A.conv1x1(s, esa.conv4.weight, esa.conv4.bias, cout_stride=cs))
+    return rec("out", A.sigmoid_gate(x, c4))
 
 
 class RepRFB(nn.Module):
@@ -295,15 +297,21 @@ class RepRFN(nn.Module):
             return self.forward_train(inputs)
         return self.infer(inputs)
 
-    def forward_train(self, inputs: Tensor) -> Tensor:
+    def forward_train(self, inputs: Tensor, trace: Optional[dict] = None) -> Tensor:
         """Differentiable forward (core/trainer.py:158-161 works unchanged): the same graph as infer(), each RepBlock
         as ONE convolution with the kernel merged from its nine branches by differentiable weight algebra, every
-        activation-space operator and its backward on the HIP kernels.  Feature maps travel padded to 64 channels."""
+        activation-space operator and its backward on the HIP kernels.  Feature maps travel padded to 64 channels.
+        ``trace`` (a dict, tests only) receives every map the pass stores, keyed by stage name."""
         from . import autograd_ops as A
+
+        def rec(name, t, prefix=""):
+            if trace is not None:
+                trace[prefix + name] = t
+            return t
         fn = self.feature_nums
         cs = 64 if fn > 32 else F_.pad16(fn)          # channel counts the weight-gradient kernel tiles: 16, 32, 64
         x = F_.nchw_f32_to_nhwc_bf16(inputs.detach().float())
-        fea = A.conv3x3(x, self.fea_conv.weight, self.fea_conv.bias, cout_stride=cs)
+        fea = rec("fea", A.conv3x3(x, self.fea_conv.weight, self.fea_conv.bias, cout_stride=cs))
         out = fea
         merged = merged_kernels_autograd(getattr(getattr(self, f"reprfb{bi}"), f"repblock{ri}")
                                          for bi in range(1, 5) for ri in range(1, 4))
@@ -311,11 +319,15 @@ class RepRFN(nn.Module):
             rfb = getattr(self, f"reprfb{bi}")
             # repblock1..3 and conv3, each with LeakyReLU, as one chain (RepRFN.py:257-262)
             layers = merged[(bi - 1) * 3:bi * 3] + [(rfb.conv3.weight, rfb.conv3.bias)]
-            t = A.add(A.conv3x3_lrelu_chain(out, layers, _SLOPE, cout_stride=cs), out)
-            out = _esa_train(rfb.esa, t)
-        out = A.add(A.conv3x3(out, self.lr_conv.weight, self.lr_conv.bias, cout_stride=cs), fea)
+            ch = A.conv3x3_lrelu_chain(out, layers, _SLOPE, cout_stride=cs)
+            if trace is not None:     # the chain's stored maps y_1 .. y_4 (its autograd node keeps x, y_1 .. y_n, W_1 .. W_n)
+                for li, y_i in enumerate(ch.grad_fn.saved_tensors[1:len(layers) + 1]):
+                    trace[f"b{bi}.chain{li + 1}"] = y_i
+            t = rec("t", A.add(ch, out), f"b{bi}.")
+            out = _esa_train(rfb.esa, t, (lambda name, tt, p=f"b{bi}.": rec(name, tt, p)) if trace is not None else None)
+        out = rec("lradd", A.add(rec("lr", A.conv3x3(out, self.lr_conv.weight, self.lr_conv.bias, cout_stride=cs)), fea))
         up = self.upsampler
-        c = A.conv3x3(out, up.conv.weight, up.conv.bias, cout_stride=64 if up.conv.out_channels > 32 else None)
+        c = rec("up", A.conv3x3(out, up.conv.weight, up.conv.bias, cout_stride=64 if up.conv.out_channels > 32 else None))
         return A.pixel_shuffle_out(c, self.out_channels, up.upscale_factor)
 
     @torch.no_grad()

@@ -14,6 +14,7 @@ autograd is done here layer by layer on NHWC bf16 tensors:
 Master weights, gradients handed to the optimiser and the network output are fp32, activations and
 activation gradients bf16 (fp32 accumulation inside every kernel).
 """
+import os
 from typing import List
 
 import torch
@@ -62,17 +63,26 @@ class _SuperSamplerFn(torch.autograd.Function):
             f.append(m._conv(f"fe{i}", blk[0], f[-1], cin))
             cin = fr
         up = F_.upsample_grid_bilinear_nhwc(f[-1], th, tw)
-        # G-buffer extractor @ HR (model.py:61-79,167); the residual sum is kept apart from its
-        # ReLU branch because the backward needs the branch's own sign pattern
+        # G-buffer extractor @ HR (model.py:61-79,167).  The backward needs the sign patterns of x = relu(conv0) and
+        # of the branch output relu(conv_b) on their own: with 64-channel layers the launches that compute them also
+        # write them out as 1 bit per element, and the residual sum x + relu(conv_b) is the second launch's epilogue;
+        # other widths keep the branch output as a map of its own and add in a separate pass.
         blks = m.gbuffers_extractor.blks
         gb = []
+        bits = bf == 64 and os.environ.get("SRHIP_NO_SIGNBITS", "0") != "1"
         prev, cin = F_.nchw_f32_to_nhwc_bf16(hb.float()), bc
         for i in range(0, len(blks), 2):
-            x = m._conv(f"ge{i}", blks[i][0], prev, cin)
-            t1 = m._conv(f"ge{i + 1}a", blks[i + 1][0][0], x, bf)
-            t2 = m._conv(f"ge{i + 1}b", blks[i + 1][1][0], t1, bf)
-            gb.append((prev, x, t1, t2))
-            prev, cin = F_.add_bf16(x, t2), bf
+            if bits:
+                x, xbits = m._conv(f"ge{i}", blks[i][0], prev, cin, aux_mode=F_.AUX_EMIT)
+                t1 = m._conv(f"ge{i + 1}a", blks[i + 1][0][0], x, bf)
+                nxt, t2 = m._conv(f"ge{i + 1}b", blks[i + 1][1][0], t1, bf, res=x, aux_mode=F_.AUX_EMIT)   # t2: sign bits only
+            else:
+                x, xbits = m._conv(f"ge{i}", blks[i][0], prev, cin), None
+                t1 = m._conv(f"ge{i + 1}a", blks[i + 1][0][0], x, bf)
+                t2 = m._conv(f"ge{i + 1}b", blks[i + 1][1][0], t1, bf)
+                nxt = F_.add_bf16(x, t2)
+            gb.append((prev, x, xbits, t1, t2))
+            prev, cin = nxt, bf
         g = prev
         # main trunk (model.py:82-95,169)
         xs = [m._conv("main_in", m.main.conv_in[0], up, fr, xb=g, cin_b=bf)]
@@ -85,7 +95,7 @@ class _SuperSamplerFn(torch.autograd.Function):
         a = m._conv("after", m.after_main[0], up, fr, xb=xs[-1], cin_b=sr)
         c0 = m._conv("fin0", m.final_conv[0], a, sr)
         out = m._conv("fin2", m.final_conv[2], c0, sr, act=F_.ACT_NONE, out_nchw_f32=True)
-        sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]))
+        sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]), bits=bits)
         ctx.model, ctx.sv = m, sv
         return out
 
@@ -127,22 +137,35 @@ class _SuperSamplerFn(torch.autograd.Function):
         _wgrad(up, d, cin_, grads, fr, ci_off=0, red=red, last=False)
         _wgrad(g, d, cin_, grads, bf, ci_off=fr, with_bias=False, red=red)
         dup = dgrad("main_in", cin_, d, lo=0, n=fr, res=dup)
-        dg = dgrad("main_in", cin_, d, lo=fr, n=bf)
-        del d, dx
-        # G-buffer extractor, last block first: out = x + relu(conv_b(relu(conv_a(x)))), x = relu(conv(prev))
+        # G-buffer extractor, last block first: out = x + relu(conv_b(relu(conv_a(x)))), x = relu(conv(prev)).
+        # dg = gradient of a block's output, dt2 = dg masked by the branch's ReLU; with sign bits both come out of the
+        # launch that computes dg, and the mask of x is applied by the launch that adds dg to the branch's gradient.
+        bits = sv["bits"]
         blks = m.gbuffers_extractor.blks
+        if bits:
+            dg, dt2 = dgrad("main_in", cin_, d, lo=fr, n=bf, signbits=gb[-1][4], aux_mode=F_.AUX_DUALBITS)
+        else:
+            dg = dgrad("main_in", cin_, d, lo=fr, n=bf)
+        del d, dx
         for b in reversed(range(len(gb))):
-            prev, x, t1, t2 = gb[b]
+            prev, x, xbits, t1, t2 = gb[b]
             conv0, conva, convb = blks[2 * b][0], blks[2 * b + 1][0][0], blks[2 * b + 1][1][0]
-            dt2 = F_.relu_mask(dg, t2)
+            if not bits:
+                dt2 = F_.relu_mask(dg, t2)
             _wgrad(t1, dt2, convb, grads, bf, red=red)
             dt1 = dgrad(f"ge{2 * b + 1}b", convb, dt2, mask=t1)
             _wgrad(x, dt1, conva, grads, bf, red=red)
-            dxb = dgrad(f"ge{2 * b + 1}a", conva, dt1, res=dg)
-            dzb = F_.relu_mask(dxb, x, out=dxb)
+            if bits:
+                dzb = dgrad(f"ge{2 * b + 1}a", conva, dt1, res=dg, signbits=xbits, aux_mode=F_.AUX_MASKBITS)
+            else:
+                dxb = dgrad(f"ge{2 * b + 1}a", conva, dt1, res=dg)
+                dzb = F_.relu_mask(dxb, x, out=dxb)
             _wgrad(prev, dzb, conv0, grads, bc if b == 0 else bf, red=red)
             if b > 0:
-                dg = dgrad(f"ge{2 * b}", conv0, dzb)
+                if bits:
+                    dg, dt2 = dgrad(f"ge{2 * b}", conv0, dzb, signbits=gb[b - 1][4], aux_mode=F_.AUX_DUALBITS)
+                else:
+                    dg = dgrad(f"ge{2 * b}", conv0, dzb)
         # frame extractor @ LR through the up-sampling (model.py:161-162)
         sh, sw = sv["lr_hw"]
         fe = m.frame_extractor.blks

@@ -28,8 +28,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_conv_args_struct_layout():
     from superresolution_amd._lib import Conv3x3Args
-    # 6 pointers + 11 4-byte scalars, padded to pointer alignment
-    assert ctypes.sizeof(Conv3x3Args) == 6 * 8 + 14 * 4
+    # 6 pointers + 14 4-byte scalars, then the sign-bit fields: pointer, int (+4 padding), pointer
+    assert ctypes.sizeof(Conv3x3Args) == 6 * 8 + 14 * 4 + 8 + 8 + 8
+    assert Conv3x3Args.aux.offset == 104 and Conv3x3Args.aux_mode.offset == 112 and Conv3x3Args.dst2.offset == 120
     assert Conv3x3Args.n.offset == 48 and Conv3x3Args.dst_nchw_f32.offset == 48 + 10 * 4 and Conv3x3Args.res_mode.offset == 92 and Conv3x3Args.ca_stride.offset == 96 and Conv3x3Args.cout_w.offset == 100
 
 
@@ -38,6 +39,8 @@ def test_packed_bytes():
     assert lib.srhip_conv3x3_packed_bytes(64, 64) == 9 * 4 * 2 * 64 * 16
     assert lib.srhip_conv3x3_packed_bytes(96, 64) == 9 * 6 * 2 * 64 * 16
     assert lib.srhip_conv3x3_packed_bytes(16, 3) == 9 * 1 * 1 * 64 * 16
+    assert lib.srhip_conv3x3_signbits_bytes(2, 3, 77) == 2 * 3 * 3 * 64 * 4      # 1 bit per element, rows padded to 32 pixels
+    assert lib.srhip_conv3x3_signbits_bytes(1, 1024, 1024) * 8 == 1024 * 1024 * 64
 
 
 def test_supersampler_state_dict_contract(ss_golden):

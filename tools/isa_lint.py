@@ -20,7 +20,7 @@ import tempfile
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"]
-LOAD_RE = re.compile(r"^(ds_read_b128|ds_read_b64_tr_b16|buffer_load_dwordx4)\s+(v\[\d+:\d+\]|v\d+)\s*,(.*)$")
+LOAD_RE = re.compile(r"^(ds_read_b128|ds_read_b64_tr_b16|buffer_load_dwordx4|buffer_load_dword)\s+(v\[\d+:\d+\]|v\d+)\s*,(.*)$")
 REG_RE = re.compile(r"\bv(?:(\d+)\b|\[(\d+):(\d+)\])")
 FENCE = "; srhip-fence"
 
