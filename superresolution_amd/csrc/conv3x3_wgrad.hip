@@ -26,6 +26,7 @@
 #include <atomic>
 
 #include "srhip_common.h"
+#define SRHIP_CAPTURE(x) (void)&(x)   // asm operands alone do not make a generic lambda capture
 
 namespace {
 
@@ -55,7 +56,7 @@ struct WCfg {
     static constexpr int XNP = round_up_i(TW + 2, XPP) / XPP;     // pieces per row
     static constexpr int ZNP = TW / ZPP;
     static constexpr int X_SLOT = XNP * 1024, Z_SLOT = ZNP * 1024;
-    static constexpr int XA = 4, ZA = 2;          // rows issued ahead
+    static constexpr int XA = 2, ZA = 2;          // rows issued ahead
     static constexpr int XRING = XA + 1, ZRING = ZA + 1;
     static constexpr int Z_BASE = XRING * X_SLOT;
     static constexpr int SINK_OFF = Z_BASE + ZRING * Z_SLOT;     // 1 KiB sink of the DMA pieces a wave does not own
@@ -63,11 +64,10 @@ struct WCfg {
     static constexpr int MAXPX = (XNP + NWAVES - 1) / NWAVES, MINPX = XNP / NWAVES;
     static constexpr int MAXPZ = (ZNP + NWAVES - 1) / NWAVES, MINPZ = ZNP / NWAVES;
     // Every wave issues exactly MAXPX + MAXPZ pieces per iteration (a piece it does not own goes,
-    // all-out-of-range, to the sink), one per tap, x pieces first.  Top of iteration i needs x row i+2
-    // and dz row i, both issued in iteration i-2: younger is exactly one whole iteration.
+    // all-out-of-range, to the sink), x pieces first.  Top of iteration r needs x row r and dz row r,
+    // both issued in iteration r-2: younger is exactly one whole iteration.
     static constexpr int TOP_WAIT = MAXPX + MAXPZ;
-    static_assert(MAXPX + MAXPZ <= 9, "one LDS-DMA piece per tap");
-    static_assert(XA >= 4 && ZA >= 2, "wait counts assume rows are issued two iterations ahead");
+    static_assert(XA == 2 && ZA == 2 && XRING == 3 && ZRING == 3, "ring slot = row % 3; wait counts assume rows issued two iterations ahead");
 };
 
 __device__ __forceinline__ void wg_lds_dma(__amdgpu_buffer_rsrc_t rsrc, __attribute__((address_space(3))) void* dst,
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (short)0x3f80;
     asm volatile("" : "+v"(ones));  // opaque: stays in four registers instead of being rebuilt next to its (asm) consumer
+    bf16x4 alo[3][C::NKS], ahi[3][C::NKS];   // dz fragments of the three newest rows
 
     for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
         const int strip = item % p.nstrips;
@@ -243,74 +244,89 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
             const unsigned so = z_soff(r);
             wg_static_for<C::MAXPX, C::MAXPX + C::MAXPZ>([&](auto m_c) { issue_piece(m_c, 0u, 0u, so, (unsigned)(C::Z_BASE + r * C::Z_SLOT)); });
         }
-        int xpos = 0, zpos = 0;  // ring slots of x row i and dz row i
+        // Iteration r works on x row r (image row y0 - 1 + r, r = 0 .. nout + 1): its fragments for the three column
+        // shifts are read from LDS ONCE and multiplied with the dz rows r, r-1, r-2 (taps ky = 0, 1, 2), whose fragments
+        // stay in registers for three iterations (slot = row % 3; the loop is unrolled by three so that every slot is a
+        // fixed set of registers).  That is one transposing LDS read pair per three MFMAs instead of one per MFMA: the
+        // LDS pipe, which four waves reading a fragment per MFMA keep busy all the time, is left with a third of the load.
+        // dz rows before the item's first are zeros; rows behind its last arrive as zeros from the DMA.
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < C::NKS; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { alo[j][k][e] = 0; ahi[j][k][e] = 0; }
 
-#pragma unroll 1
-        for (int i = 0; i < nout; ++i) {
-            if (i < 2) wg_vm_wait<0>();
+        auto row_body = [&](auto ph_c, const int r) {
+            SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(accb);
+            constexpr int PH = decltype(ph_c)::value;   // r % 3: ring slot of x row r and dz row r, register slot of dz row r
+            if (r < 2) wg_vm_wait<0>();
             else wg_vm_wait<C::TOP_WAIT>();
             __builtin_amdgcn_s_barrier();
-            // rows fetched during this iteration go to the slots that row i-1 just left
-            const unsigned dxs = x_soff(i + C::XA), dzs = z_soff(i + C::ZA);
-            const unsigned dxslot = (unsigned)((xpos == 0 ? C::XRING - 1 : xpos - 1) * C::X_SLOT);
-            const unsigned dzslot = (unsigned)(C::Z_BASE + (zpos == 0 ? C::ZRING - 1 : zpos - 1) * C::Z_SLOT);
+            // rows fetched during this iteration go to the slots that row r-1 just left
+            const unsigned dxs = x_soff(r + C::XA), dzs = z_soff(r + C::ZA);
+            constexpr unsigned dxslot = (unsigned)(((PH + 2) % 3) * C::X_SLOT);
+            constexpr unsigned dzslot = (unsigned)(C::Z_BASE + ((PH + 2) % 3) * C::Z_SLOT);
 
-            // per-row read bases: everything else is an immediate offset of the LDS instruction
-            unsigned xb[3][3][2], zb[2];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int sl = xpos + ky;
-                const unsigned rowoff = (unsigned)((sl >= C::XRING ? sl - C::XRING : sl) * C::X_SLOT);
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    xb[ky][kx][0] = xaddr[kx][0] + rowoff;
-                    xb[ky][kx][1] = xaddr[kx][1] + rowoff;
-                }
-            }
-            zb[0] = zaddr[0] + (unsigned)(zpos * C::Z_SLOT);
-            zb[1] = zaddr[1] + (unsigned)(zpos * C::Z_SLOT);
-            xpos = (xpos + 1 == C::XRING) ? 0 : xpos + 1;
-            zpos = (zpos + 1 == C::ZRING) ? 0 : zpos + 1;
-
-            // dz fragments of this row (reused by all 9 taps)
-            bf16x4 alo[C::NKS], ahi[C::NKS];
+            // dz fragments of row r -> register slot PH
             wg_static_for<0, C::NKS>([&](auto s_c) {
-                constexpr int s = decltype(s_c)::value;
-                alo[s] = lds_read_tr<s * 16 * C::ZPB>(zb[0]);
-                ahi[s] = lds_read_tr<s * 16 * C::ZPB>(zb[1]);
+                SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi);
+                constexpr int sk = decltype(s_c)::value;
+                alo[PH][sk] = lds_read_tr<PH * C::Z_SLOT + sk * 16 * C::ZPB>(zaddr[0]);
+                ahi[PH][sk] = lds_read_tr<PH * C::Z_SLOT + sk * 16 * C::ZPB>(zaddr[1]);
             });
-            // x fragments run one step ahead of the MFMAs
-            constexpr int NSTEP = 9 * C::NKS;
-            bf16x4 blo[2], bhi[2];
-            blo[0] = lds_read_tr<0>(xb[0][0][0]);
-            bhi[0] = lds_read_tr<0>(xb[0][0][1]);
-            wg_static_for<0, NSTEP>([&](auto st_c) {
+            // x fragments run two steps ahead of the MFMAs
+            constexpr int NSTEP = 3 * C::NKS;
+            constexpr int NP = C::MAXPX + C::MAXPZ, PPS = (NP + NSTEP - 1) / NSTEP;
+            bf16x4 blo[3], bhi[3];
+            wg_static_for<0, 2>([&](auto st_c) {
+                SRHIP_CAPTURE(blo); SRHIP_CAPTURE(bhi);
                 constexpr int st = decltype(st_c)::value;
-                constexpr int t = st / C::NKS, s = st % C::NKS;
-                constexpr int cur = st & 1, nxt = cur ^ 1;
-                if constexpr (st + 1 < NSTEP) {
-                    constexpr int tn = (st + 1) / C::NKS, sn = (st + 1) % C::NKS;
-                    blo[nxt] = lds_read_tr<sn * 16 * C::XPB>(xb[tn / 3][tn % 3][0]);
-                    bhi[nxt] = lds_read_tr<sn * 16 * C::XPB>(xb[tn / 3][tn % 3][1]);
+                blo[st] = lds_read_tr<PH * C::X_SLOT + (st % C::NKS) * 16 * C::XPB>(xaddr[st / C::NKS][0]);
+                bhi[st] = lds_read_tr<PH * C::X_SLOT + (st % C::NKS) * 16 * C::XPB>(xaddr[st / C::NKS][1]);
+            });
+            wg_static_for<0, NSTEP>([&](auto st_c) {
+                SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(accb); SRHIP_CAPTURE(blo); SRHIP_CAPTURE(bhi);
+                constexpr int st = decltype(st_c)::value;
+                constexpr int kx = st / C::NKS, sk = st % C::NKS;
+                constexpr int cur = st % 3;
+                if constexpr (st + 2 < NSTEP) {
+                    constexpr int sn = st + 2, nb = sn % 3;
+                    blo[nb] = lds_read_tr<PH * C::X_SLOT + (sn % C::NKS) * 16 * C::XPB>(xaddr[sn / C::NKS][0]);
+                    bhi[nb] = lds_read_tr<PH * C::X_SLOT + (sn % C::NKS) * 16 * C::XPB>(xaddr[sn / C::NKS][1]);
+                    wg_lds_wait<4>();
+                } else if constexpr (st + 1 < NSTEP) {
                     wg_lds_wait<2>();
                 } else {
-                    wg_lds_wait<0>();
+                    wg_lds_wait<0>();   // nothing stays in flight across the end of a row
                 }
-                if constexpr (st == 0) {
+                if constexpr (st == 0) {  // the dz reads are older than every x read
 #pragma unroll
-                    for (int k = 0; k < C::NKS; ++k) { SRHIP_LOAD_FENCE(alo[k]); SRHIP_LOAD_FENCE(ahi[k]); }
+                    for (int k = 0; k < C::NKS; ++k) { SRHIP_LOAD_FENCE(alo[PH][k]); SRHIP_LOAD_FENCE(ahi[PH][k]); }
                 }
                 SRHIP_LOAD_FENCE(blo[cur]);  // consumers stay behind the wait
                 SRHIP_LOAD_FENCE(bhi[cur]);
-                const bf16x8 a = join(alo[s], ahi[s]);
                 const bf16x8 b = join(blo[cur], bhi[cur]);
-                wg_mfma<t>(acc[t], a, b);
-                if constexpr (t == 4) {
-                    if (cit == 0) wg_mfma<9>(accb, a, ones);
+                wg_static_for<0, 3>([&](auto ky_c) {
+                    SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi); SRHIP_CAPTURE(acc);
+                    constexpr int ky = decltype(ky_c)::value;
+                    constexpr int sl = (PH + 3 - ky) % 3;    // dz row r - ky
+                    wg_mfma<ky * 3 + kx>(acc[ky * 3 + kx], join(alo[sl][sk], ahi[sl][sk]), b);
+                });
+                if constexpr (kx == 1) {
+                    if (cit == 0) wg_mfma<9>(accb, join(alo[PH][sk], ahi[PH][sk]), ones);
                 }
-                // one LDS-DMA piece per tap, after the tap's first MFMA
-                if constexpr (s == 0 && t < C::MAXPX + C::MAXPZ) issue_piece(WIntC<t + 0 * st>{}, dxs, dxslot, dzs, dzslot);
+                // the LDS-DMA pieces of the rows two iterations ahead, spread over the first steps
+                wg_static_for<st * PPS, ((st + 1) * PPS < NP ? (st + 1) * PPS : NP)>([&](auto m_c) {
+                    issue_piece(WIntC<decltype(m_c)::value + 0 * st>{}, dxs, dxslot, dzs, dzslot);
+                });
             });
+        };
+#pragma unroll 1
+        for (int r = 0; r < nout + 2; r += 3) {
+            row_body(WIntC<0>{}, r);
+            if (r + 1 < nout + 2) row_body(WIntC<1>{}, r + 1);
+            if (r + 2 < nout + 2) row_body(WIntC<2>{}, r + 2);
         }
         wg_vm_wait<0>();  // look-ahead rows past the item's end were issued as all-zero rows
     }

@@ -16,4 +16,7 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out/pmc4 -o p -- python3 tool
 timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $out/pmc5 -o p -- python3 tools/prof_pair.py > $out/pmc5.log 2>&1 || exit 7
 for i in 1 2 3 4 5; do python3 tools/rocpd_summary.py pmc $(find $out/pmc$i -name "*.db" | head -1) pair; done > $out/pair_pmc.csv
 cat $out/pair_pmc.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_train -o bench -- python3 bench.py --workload train --steps 4 --warmup 2 --no-cpu-baseline > $out/trace_train.log 2>&1 || exit 8
+python3 tools/rocpd_summary.py stats $(find $out/trace_train -name "*.db" | head -1) > $out/train_kernel_stats.csv || exit 81
+head -30 $out/train_kernel_stats.csv
 echo done
