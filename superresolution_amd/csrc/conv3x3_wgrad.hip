@@ -56,7 +56,7 @@ struct WCfg {
     static constexpr int XNP = round_up_i(TW + 2, XPP) / XPP;     // pieces per row
     static constexpr int ZNP = TW / ZPP;
     static constexpr int X_SLOT = XNP * 1024, Z_SLOT = ZNP * 1024;
-    static constexpr int XA = 2, ZA = 2;          // rows issued ahead
+    static constexpr int XA = 3, ZA = 3;          // rows issued ahead
     static constexpr int XRING = XA + 1, ZRING = ZA + 1;
     static constexpr int Z_BASE = XRING * X_SLOT;
     static constexpr int SINK_OFF = Z_BASE + ZRING * Z_SLOT;     // 1 KiB sink of the DMA pieces a wave does not own
@@ -65,9 +65,10 @@ struct WCfg {
     static constexpr int MAXPZ = (ZNP + NWAVES - 1) / NWAVES, MINPZ = ZNP / NWAVES;
     // Every wave issues exactly MAXPX + MAXPZ pieces per iteration (a piece it does not own goes,
     // all-out-of-range, to the sink), x pieces first.  Top of iteration r needs x row r and dz row r,
-    // both issued in iteration r-2: younger is exactly one whole iteration.
-    static constexpr int TOP_WAIT = MAXPX + MAXPZ;
-    static_assert(XA == 2 && ZA == 2 && XRING == 3 && ZRING == 3, "ring slot = row % 3; wait counts assume rows issued two iterations ahead");
+    // both issued in iteration r-XA: younger are exactly XA-1 whole iterations.
+    static constexpr int TOP_WAIT = (XA - 1) * (MAXPX + MAXPZ);
+    static_assert(XA == ZA && XA >= 2, "wait counts assume both rings run the same distance ahead");
+    static_assert(LDS_BYTES <= 160 * 1024, "rings exceed the CU's LDS");
 };
 
 __device__ __forceinline__ void wg_lds_dma(__amdgpu_buffer_rsrc_t rsrc, __attribute__((address_space(3))) void* dst,
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
         }
         // Iteration r works on x row r (image row y0 - 1 + r, r = 0 .. nout + 1): its fragments for the three column
         // shifts are read from LDS ONCE and multiplied with the dz rows r, r-1, r-2 (taps ky = 0, 1, 2), whose fragments
-        // stay in registers for three iterations (slot = row % 3; the loop is unrolled by three so that every slot is a
-        // fixed set of registers).  That is one transposing LDS read pair per three MFMAs instead of one per MFMA: the
+        // stay in registers for three iterations (register slot = row % 3; the loop is unrolled by three so that every
+        // slot is a fixed set of registers).  That is one transposing LDS read pair per three MFMAs instead of one per MFMA: the
         // LDS pipe, which four waves reading a fragment per MFMA keep busy all the time, is left with a third of the load.
         // dz rows before the item's first are zeros; rows behind its last arrive as zeros from the DMA.
 #pragma unroll
@@ -257,23 +258,33 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { alo[j][k][e] = 0; ahi[j][k][e] = 0; }
 
+        int ring = 0;   // ring slot of x row r and of dz row r (both rings have XRING slots)
         auto row_body = [&](auto ph_c, const int r) {
             SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(accb);
-            constexpr int PH = decltype(ph_c)::value;   // r % 3: ring slot of x row r and dz row r, register slot of dz row r
-            if (r < 2) wg_vm_wait<0>();
+            constexpr int PH = decltype(ph_c)::value;   // r % 3: register slot of dz row r
+            if (r < C::XA) wg_vm_wait<0>();
             else wg_vm_wait<C::TOP_WAIT>();
             __builtin_amdgcn_s_barrier();
             // rows fetched during this iteration go to the slots that row r-1 just left
             const unsigned dxs = x_soff(r + C::XA), dzs = z_soff(r + C::ZA);
-            constexpr unsigned dxslot = (unsigned)(((PH + 2) % 3) * C::X_SLOT);
-            constexpr unsigned dzslot = (unsigned)(C::Z_BASE + ((PH + 2) % 3) * C::Z_SLOT);
+            const unsigned dxslot = (unsigned)((ring == 0 ? C::XRING - 1 : ring - 1) * C::X_SLOT);
+            const unsigned dzslot = (unsigned)(C::Z_BASE + (ring == 0 ? C::ZRING - 1 : ring - 1) * C::Z_SLOT);
+            // per-row read bases: everything else is an immediate offset of the LDS instruction
+            unsigned xa[3][2], za[2];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                za[j2] = zaddr[j2] + (unsigned)(ring * C::Z_SLOT);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) xa[kx][j2] = xaddr[kx][j2] + (unsigned)(ring * C::X_SLOT);
+            }
+            ring = (ring + 1 == C::XRING) ? 0 : ring + 1;
 
             // dz fragments of row r -> register slot PH
             wg_static_for<0, C::NKS>([&](auto s_c) {
                 SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi);
                 constexpr int sk = decltype(s_c)::value;
-                alo[PH][sk] = lds_read_tr<PH * C::Z_SLOT + sk * 16 * C::ZPB>(zaddr[0]);
-                ahi[PH][sk] = lds_read_tr<PH * C::Z_SLOT + sk * 16 * C::ZPB>(zaddr[1]);
+                alo[PH][sk] = lds_read_tr<sk * 16 * C::ZPB>(za[0]);
+                ahi[PH][sk] = lds_read_tr<sk * 16 * C::ZPB>(za[1]);
             });
             // x fragments run two steps ahead of the MFMAs
             constexpr int NSTEP = 3 * C::NKS;
@@ -282,8 +293,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
             wg_static_for<0, 2>([&](auto st_c) {
                 SRHIP_CAPTURE(blo); SRHIP_CAPTURE(bhi);
                 constexpr int st = decltype(st_c)::value;
-                blo[st] = lds_read_tr<PH * C::X_SLOT + (st % C::NKS) * 16 * C::XPB>(xaddr[st / C::NKS][0]);
-                bhi[st] = lds_read_tr<PH * C::X_SLOT + (st % C::NKS) * 16 * C::XPB>(xaddr[st / C::NKS][1]);
+                blo[st] = lds_read_tr<(st % C::NKS) * 16 * C::XPB>(xa[st / C::NKS][0]);
+                bhi[st] = lds_read_tr<(st % C::NKS) * 16 * C::XPB>(xa[st / C::NKS][1]);
             });
             wg_static_for<0, NSTEP>([&](auto st_c) {
                 SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(accb); SRHIP_CAPTURE(blo); SRHIP_CAPTURE(bhi);
@@ -292,8 +303,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                 constexpr int cur = st % 3;
                 if constexpr (st + 2 < NSTEP) {
                     constexpr int sn = st + 2, nb = sn % 3;
-                    blo[nb] = lds_read_tr<PH * C::X_SLOT + (sn % C::NKS) * 16 * C::XPB>(xaddr[sn / C::NKS][0]);
-                    bhi[nb] = lds_read_tr<PH * C::X_SLOT + (sn % C::NKS) * 16 * C::XPB>(xaddr[sn / C::NKS][1]);
+                    blo[nb] = lds_read_tr<(sn % C::NKS) * 16 * C::XPB>(xa[sn / C::NKS][0]);
+                    bhi[nb] = lds_read_tr<(sn % C::NKS) * 16 * C::XPB>(xa[sn / C::NKS][1]);
                     wg_lds_wait<4>();
                 } else if constexpr (st + 1 < NSTEP) {
                     wg_lds_wait<2>();
