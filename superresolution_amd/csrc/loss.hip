@@ -175,15 +175,26 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const LossParams p)
     }
 }
 
-__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nblocks, float inv_n, float lambda_l1,
-                                     float lambda_ssim, float* __restrict__ out)
+// One work-group of 1024 threads; every thread sums its partials four at a time (independent loads in flight: a
+// dependent chain of ~100 global loads per thread took 41 us for the 24,300 tiles of a 4K frame), then a fixed-order
+// tree in LDS: deterministic from run to run.
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __restrict__ partial, int nblocks, float inv_n, float lambda_l1,
+                                                             float lambda_ssim, float* __restrict__ out)
 {
-    __shared__ double rs[256], rl[256];
+    __shared__ double rs[1024], rl[1024];
+    struct __attribute__((packed, aligned(4))) Pair { float x, y; };   // the partials start at a 4-byte-aligned address
+    const Pair* p2 = (const Pair*)partial;       // (ssim sum, l1 sum) per tile
     double s = 0.0, l = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) { s += partial[2 * i]; l += partial[2 * i + 1]; }
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < nblocks; i += 4 * 1024) {
+        const Pair a = p2[i], b = p2[i + 1024], c = p2[i + 2048], d = p2[i + 3072];
+        s += ((double)a.x + (double)b.x) + ((double)c.x + (double)d.x);
+        l += ((double)a.y + (double)b.y) + ((double)c.y + (double)d.y);
+    }
+    for (; i < nblocks; i += 1024) { const Pair a = p2[i]; s += a.x; l += a.y; }
     rs[threadIdx.x] = s; rl[threadIdx.x] = l;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = 512; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rl[threadIdx.x] += rl[threadIdx.x + off]; }
         __syncthreads();
     }
@@ -240,7 +251,7 @@ SRHIP_API int srhip_l1_ssim_loss(const float* sr, const float* target, float* ds
     hipLaunchKernelGGL(ssim_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, p);
     rc = srhip_check_launch("ssim_bwd_kernel");
     if (rc != SRHIP_OK) return rc;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, p.partial, (int)nblocks, (float)(1.0 / n), lambda_l1,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, p.partial, (int)nblocks, (float)(1.0 / n), lambda_l1,
                        lambda_ssim, out3);
     return srhip_check_launch("loss_finalize_kernel");
 }

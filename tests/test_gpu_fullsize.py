@@ -251,3 +251,58 @@ def test_temporal_variant_4k_is_finite_and_reproducible():
     hb = base[1].clone().cuda()
     m.infer(base[0].cuda(), hb, base[2].clone().cuda(), base[3].cuda(), base[4].cuda(), base[5].clone().cuda())
     assert torch.equal(hb[:, :9].cpu(), base[1][:, :9]) and float(hb[:, 9].max()) < 10.0 and not torch.equal(hb[:, 9].cpu(), base[1][:, 9])
+
+
+def test_warp_4k_three_channels_zero_and_integer_motion():
+    """backward_warping (core/tools/math.py:10-17) of a 3-channel 2160x3840 frame, properties that need no oracle:
+    nearest mode with zero motion is the identity and with an integer shift a shifted copy with a zero border, bit for
+    bit; bilinear mode lands within the rounding of the reference's normalise / un-normalise arithmetic (the sampling
+    position of pixel x is x + m up to 1e-4 pixel, so the neighbour's weight is at most that)."""
+    from superresolution_amd import functional as F_
+    g = torch.Generator().manual_seed(3)
+    h, w = 2160, 3840
+    fr = torch.rand(1, 3, h, w, generator=g).cuda()
+    zero = torch.zeros(1, 2, h, w, device="cuda")
+    assert torch.equal(F_.backward_warp(fr, zero, "nearest", True), fr)
+    assert float((F_.backward_warp(fr, zero, "bilinear", True) - fr).abs().max()) <= 5e-4
+    for dx, dy in ((7, -3), (-64, 40)):
+        mv = torch.zeros(1, 2, h, w, device="cuda")
+        mv[:, 0], mv[:, 1] = float(dx), float(dy)
+        ref = torch.zeros_like(fr)
+        ys, ye = max(0, -dy), min(h, h - dy)
+        xs, xe = max(0, -dx), min(w, w - dx)
+        ref[:, :, ys:ye, xs:xe] = fr[:, :, ys + dy:ye + dy, xs + dx:xe + dx]
+        assert torch.equal(F_.backward_warp(fr, mv, "nearest", True), ref)
+        got = F_.backward_warp(fr, mv, "bilinear", True)
+        inner = (slice(None), slice(None), slice(ys + 1, ye - 1), slice(xs + 1, xe - 1))
+        assert float((got[inner] - ref[inner]).abs().max()) <= 5e-4
+        outside = torch.ones_like(fr, dtype=torch.bool)
+        outside[:, :, max(0, ys - 1):ye + 1, max(0, xs - 1):xe + 1] = False
+        assert float(got[outside].abs().max()) == 0.0
+    # the bf16 NHWC form gives the same picture as the fp32 form on the same (bf16-representable) values
+    fr16 = fr[:, :, :540, :960].to(torch.bfloat16)
+    nhwc = torch.zeros(1, 540, 960, 8, dtype=torch.bfloat16, device="cuda")
+    nhwc[..., :3] = fr16.permute(0, 2, 3, 1)
+    mv = (torch.randn(1, 2, 540, 960, generator=g) * 4).cuda()
+    a = F_.backward_warp_nhwc(nhwc, mv, "bilinear", True)[..., :3].permute(0, 3, 1, 2).float()
+    b = F_.backward_warp(fr16.float().contiguous(), mv, "bilinear", True)
+    assert torch.equal(a, b.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("ratio", [2, 4])
+@pytest.mark.parametrize("shape", [(1, 5, 37, 8), (2, 33, 64, 32), (1, 1, 1, 16), (1, 270, 480, 32)])
+def test_integer_ratio_upsample_equals_the_general_sampler(ratio, shape):
+    """The R x R-outputs-per-thread form of the fixed-ratio up-sampling (core/models/model.py:153,162) against the
+    fp32 sampler on the same bf16 values: same taps, same weights, same order of additions, so after rounding to bf16
+    the maps are equal bit for bit; a non-integer ratio takes the general bf16 kernel and must agree with it too."""
+    from superresolution_amd import functional as F_
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(h * w + c)
+    x = (torch.rand(n, h, w, c, generator=g) - 0.5).to(torch.bfloat16).cuda()
+    got = F_.upsample_grid_bilinear_nhwc(x, ratio * h, ratio * w)
+    ref = F_.upsample_grid_bilinear(x.float().permute(0, 3, 1, 2).contiguous(), ratio * h, ratio * w)
+    assert torch.equal(got.permute(0, 3, 1, 2).float(), ref.to(torch.bfloat16).float())
+    if h > 1:
+        got3 = F_.upsample_grid_bilinear_nhwc(x, 3 * h, 3 * w)           # general kernel
+        ref3 = F_.upsample_grid_bilinear(x.float().permute(0, 3, 1, 2).contiguous(), 3 * h, 3 * w)
+        assert torch.equal(got3.permute(0, 3, 1, 2).float(), ref3.to(torch.bfloat16).float())

@@ -46,6 +46,8 @@ def suite(verbose=True):
          (2 * 3 + 2) * H * W * 4)
     fr16 = bf(1, H, W, 16)
     line("warp bilinear bf16 NHWC 16ch @4K", timeit(lambda: F_.backward_warp_nhwc(fr16, mv, "bilinear", True)), 2 * 16 * H * W * 2 + 2 * H * W * 4)
+    line("warp bilinear bf16 NHWC 16ch @4K, smooth motion", timeit(lambda: F_.backward_warp_nhwc(fr16, smooth, "bilinear", True)),
+         2 * 16 * H * W * 2 + 2 * H * W * 4)
     # reference-shaped LR warp: 13 channels (frames + buffers) at 540x960
     fl, ml = bf(1, h, w, 16), torch.randn(1, 2, h, w, device=dev)
     line("warp bilinear bf16 NHWC 16ch @LR", timeit(lambda: F_.backward_warp_nhwc(fl, ml, "bilinear", True)), 2 * 16 * h * w * 2 + 2 * h * w * 4)
