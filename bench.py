@@ -716,6 +716,10 @@ def main():
             res["roofline"] = single
         if train is not None:
             res["train"] = train   # second half of the metric: train crops/s at this GPU count (weak scaling)
+        # the memory-bound neighbours of the path at the 4K shapes (algorithmic GB/s; `--workload memops` has them all)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_memops
+        res.update(bench_memops.headline())
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_crop)
         emit(args, res)

@@ -34,7 +34,7 @@ struct LossParams {
     float* abc;      // workspace: 3 maps of planes*h*w floats
     float* partial;  // workspace: 2 floats per block
     float* dsr;
-    int planes, h, w, tiles_x, tiles_y;
+    int planes, h, w, tiles_x, tiles_y, ntiles;
     float clip_min, clip_max;
     float g_ssim, g_l1;  // -lambda_ssim / N,  lambda_l1 / N
     Gauss g;
@@ -49,7 +49,13 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const LossParams p)
     __shared__ float hb[5][EXT][TILE + 1];
     __shared__ float red[2][4];
     const int tid = threadIdx.x;
-    int b = blockIdx.x;
+    // Tiles in XCD bands: work-group g takes tile (g % 8) * ceil(tiles / 8) + g / 8, so each of the 8 XCDs (one L2
+    // each, work-groups dealt round-robin) owns a contiguous run of tiles and the 5-pixel halos of neighbouring tiles
+    // are served by its own L2 (with the natural order the fetch traffic was 3x the algorithmic reads).
+    const int per = (p.ntiles + 7) >> 3;
+    int b = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (b >= p.ntiles) return;
+    const int tile_id = b;
     const int tx = b % p.tiles_x; b /= p.tiles_x;
     const int ty = b % p.tiles_y;
     const int plane = b / p.tiles_y;
@@ -115,8 +121,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const LossParams p)
     if ((tid & 63) == 0) { red[0][tid >> 6] = s_sum; red[1][tid >> 6] = l_sum; }
     __syncthreads();
     if (tid == 0) {
-        p.partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        p.partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        p.partial[2 * tile_id] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p.partial[2 * tile_id + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
@@ -125,7 +131,13 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const LossParams p)
     __shared__ float sm[3][EXT][EXT + 1];
     __shared__ float hb[3][EXT][TILE + 1];
     const int tid = threadIdx.x;
-    int b = blockIdx.x;
+    // Tiles in XCD bands: work-group g takes tile (g % 8) * ceil(tiles / 8) + g / 8, so each of the 8 XCDs (one L2
+    // each, work-groups dealt round-robin) owns a contiguous run of tiles and the 5-pixel halos of neighbouring tiles
+    // are served by its own L2 (with the natural order the fetch traffic was 3x the algorithmic reads).
+    const int per = (p.ntiles + 7) >> 3;
+    int b = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (b >= p.ntiles) return;
+    
     const int tx = b % p.tiles_x; b /= p.tiles_x;
     const int ty = b % p.tiles_y;
     const int plane = b / p.tiles_y;
@@ -245,10 +257,12 @@ SRHIP_API int srhip_l1_ssim_loss(const float* sr, const float* target, float* ds
     }
     for (int i = 0; i < WIN; ++i) p.g.w[i] = gs[i] / sum;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, p);
+    p.ntiles = (int)nblocks;
+    const unsigned grid = (unsigned)((nblocks + 7) / 8 * 8);
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(grid), dim3(256), 0, s, p);
     int rc = srhip_check_launch("ssim_fwd_kernel");
     if (rc != SRHIP_OK) return rc;
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(grid), dim3(256), 0, s, p);
     rc = srhip_check_launch("ssim_bwd_kernel");
     if (rc != SRHIP_OK) return rc;
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, p.partial, (int)nblocks, (float)(1.0 / n), lambda_l1,

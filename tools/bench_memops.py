@@ -22,6 +22,24 @@ def timeit(fn, iters=10):
     return ts[len(ts) // 2]
 
 
+def headline():
+    """The two operator figures BASELINE.json's configs ask for next to the frame rate (config 5: warp and pixel
+    shuffle at the 4K shapes) -> {"warp_gbps", "warp_smooth_motion_gbps", "pixel_shuffle_gbps", "pixel_shuffle_head_gbps"}
+    (algorithmic GB/s, median of 10 launches each)."""
+    f32 = lambda *s: torch.rand(*s, device=dev)
+    fr, mv = f32(1, 3, H, W), (torch.randn(1, 2, H, W, device=dev) * 4).clamp(-32, 32)
+    smooth = torch.nn.functional.interpolate(torch.randn(1, 2, 28, 48, device=dev) * 4, size=(H, W), mode="bilinear",
+                                             align_corners=True).clamp(-32, 32).contiguous()
+    nb = (2 * 3 + 2) * H * W * 4
+    out = {"warp_gbps": nb / timeit(lambda: F_.backward_warp(fr, mv, "bilinear", True)) / 1e6,
+           "warp_smooth_motion_gbps": nb / timeit(lambda: F_.backward_warp(fr, smooth, "bilinear", True)) / 1e6}
+    x = f32(1, 48, h, w)
+    out["pixel_shuffle_gbps"] = 2 * 48 * h * w * 4 / timeit(lambda: F_.pixel_shuffle(x, 4)) / 1e6
+    head = (torch.rand(1, h, w, 48, device=dev) - 0.5).to(torch.bfloat16)
+    out["pixel_shuffle_head_gbps"] = (48 * h * w * 2 + 3 * H * W * 4) / timeit(lambda: F_.pixel_shuffle_nhwc_to_nchw_f32(head, 3, 4)) / 1e6
+    return out
+
+
 def suite(verbose=True):
     """-> list of {"op", "ms", "bytes", "gbps", "frac_of_hbm_peak"} (median of 10 launches each)."""
     results = []
