@@ -151,6 +151,41 @@ typedef struct {
 } srhip_conv3x3_pair_args;
 SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * General convolution as one implicit GEMM on the matrix cores: nn.Conv2d with kernel 1 or 3, stride 1 or 2,
+ * padding 0 or 1, any channel counts, for the layers outside the shape of srhip_conv3x3_fwd:
+ * core/models/model_final.py:237-246 (160 -> 160 1x1), :272-276 and :329-363 (up to 384 -> 256 channels, 3x3 stride 2
+ * down-sampling, torch.concat of up to three maps in front of a layer, :375-379), core/arch/RepRFN.py:285-291.
+ *
+ *   dst = alpha * act(conv(concat(src[0..nsrc-1])) + bias) + res        fp32 accumulation over the whole reduction
+ *
+ *   src[k]:     NHWC bf16 map; c[k] channels (multiple of 16) are read from each pixel, whose tensor holds cstride[k]
+ *               channels per pixel (so a channel slice of a wider tensor can be a source)
+ *   wpack:      srhip_conv_gemm_pack_weights(weight (cout, cin, k, k) fp32, ..., cin_padded = sum of c[k]); input channel
+ *               positions >= cin carry zero weights (channel padding of the last source)
+ *   bias:       cout fp32 or NULL;  res: NULL or a tensor of dst's layout, added after activation and alpha
+ *   dst:        (n, ho, wo, cout_stride) bf16, ho = (h + 2 pad - k) / stride + 1; channels [0, pad16(cout)) are written
+ *   alpha > 0;  act / slope as in srhip_conv3x3_args */
+typedef struct {
+    const void* src[3];
+    int c[3];
+    int cstride[3];
+    int nsrc;
+    const void* wpack;
+    const float* bias;
+    const void* res;
+    void* dst;
+    int n, h, w;
+    int cout, cout_stride;
+    int ksize, stride, pad;
+    int act;
+    float slope, alpha;
+} srhip_conv_gemm_args;
+SRHIP_API size_t srhip_conv_gemm_packed_bytes(int cin_padded, int cout, int ksize);
+SRHIP_API int srhip_conv_gemm_pack_weights(const float* weight, void* packed, int cout, int cin, int ksize, int cin_padded,
+                                           void* stream);
+SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* args, void* stream);
+
 /* Weight and bias gradient of the same layer (autograd backward of nn.Conv2d,
  * core/models/model.py:12,26-28,112-114 via loss.backward() at core/trainer.py:160):
  *   dw[co][ci_off+ci][ky][kx] (=|+=) scale * sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]

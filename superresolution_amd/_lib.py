@@ -57,6 +57,16 @@ class Conv3x3PairArgs(ctypes.Structure):
     ]
 
 
+class ConvGemmArgs(ctypes.Structure):
+    """srhip_conv_gemm_args"""
+    _fields_ = [
+        ("src", c_void_p * 3), ("c", c_int * 3), ("cstride", c_int * 3), ("nsrc", c_int),
+        ("wpack", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("dst", c_void_p),
+        ("n", c_int), ("h", c_int), ("w", c_int), ("cout", c_int), ("cout_stride", c_int),
+        ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("act", c_int), ("slope", c_float), ("alpha", c_float),
+    ]
+
+
 _SIGNATURES = {
     "srhip_version": (c_int, []),
     "srhip_last_error": (ctypes.c_char_p, []),
@@ -68,6 +78,9 @@ _SIGNATURES = {
                                            c_int, c_int, c_void_p]),
     "srhip_conv3x3_fwd": (c_int, [ctypes.POINTER(Conv3x3Args), c_void_p]),
     "srhip_conv3x3_pair_fwd": (c_int, [ctypes.POINTER(Conv3x3PairArgs), c_void_p]),
+    "srhip_conv_gemm_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "srhip_conv_gemm_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "srhip_conv_gemm_fwd": (c_int, [ctypes.POINTER(ConvGemmArgs), c_void_p]),
     "srhip_conv3x3_wgrad_workspace_bytes": (c_size_t, []),
     "srhip_conv3x3_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float, c_void_p]),
     "srhip_conv2d_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 +

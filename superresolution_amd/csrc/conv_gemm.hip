@@ -1,0 +1,305 @@
+// General convolution as an implicit GEMM on the matrix cores, for the layers that are not the 3x3 / stride 1 /
+// <= 64-channel shape of conv3x3_mfma.hip: the temporal network's wide, strided and 1x1 layers
+// (core/models/model_final.py:237-246 G-buffer encoder 160 -> 160 1x1, :272-276 / :329-363 encoder-decoder layers
+// with up to 384 input and 256 output channels, 3x3 stride 2 down-sampling) and RepRFN's ESA 1x1 / strided layers
+// (core/arch/RepRFN.py:285-291).
+//
+//   dst = alpha * act(conv_{k x k, stride s, pad p}(concat(src_0, src_1, src_2)) + bias) + res
+//
+// NHWC bf16 activations, fp32 accumulation over the WHOLE reduction (all taps, all input channels of all sources) in
+// one launch: no partial sums leave the registers.  k in {1, 3}, s in {1, 2}, p in {0, 1}.
+//
+//   * A work-group (4 waves) computes 128 pixels of one output row x up to 128 output channels (4 MFMA tiles of 32);
+//     wave w owns pixels 32w .. 32w+31 for all of them: 4 accumulators of 16 registers.
+//   * The reduction runs over 16-channel chunks of the concatenated input.  Per chunk the work-group stages in LDS
+//     the input window (k rows x ((128-1)s + k) pixels x 32 B; rows and columns outside the image as zeros) and the
+//     chunk's weights for all k*k taps (k*k x 4 fragments of 1 KiB, already in MFMA operand order), then every wave
+//     issues k*k x 4 MFMAs from ds_read_b128 fragments.  The next chunk's global loads are issued before the MFMAs of
+//     the current one and held in registers, so HBM/L2 latency hides behind the matrix work.
+//   * The concatenation of up to three maps (skip connections, model_final.py:375-379) is read in place: a chunk
+//     comes from the map that holds it.
+//   * Epilogue straight from the accumulators: lane (pixel, 4 consecutive channels) -> bias, activation, alpha,
+//     residual, bf16 pack, one 8-byte store.
+#include <atomic>
+
+#include "srhip_common.h"
+
+namespace {
+
+constexpr int TPX = 128;    // output pixels per work-group
+constexpr int MAXNT = 4;    // 32-channel output tiles per work-group
+constexpr int NTHREADS = 256;
+
+struct GemmSrc {
+    const char* p;
+    int c;         // channels read from this map (multiple of 16)
+    int cstride;   // channels per pixel of the tensor it lives in
+};
+
+struct GemmParams {
+    GemmSrc src[3];
+    int nsrc;
+    const char* wpack;
+    const float* bias;
+    const char* res;
+    char* dst;
+    int n, h, w, ho, wo;
+    int kc_total, ct_total;   // 16-channel input chunks, 32-channel output tiles of the packed weights
+    int cout, cout_w, cout_stride;
+    int pad;
+    float slope, alpha;
+};
+
+template <int KS, int S>
+struct GCfg {
+    static constexpr int T = KS * KS;
+    static constexpr int PX = (TPX - 1) * S + KS;                   // input pixels per staged row
+    static constexpr int XPIECES = KS * PX * 2;                     // 16-byte pieces of the input window
+    static constexpr int NXP = (XPIECES + NTHREADS - 1) / NTHREADS; // per thread
+    static constexpr int WPIECES = T * MAXNT * 64;
+    static constexpr int NWP = (WPIECES + NTHREADS - 1) / NTHREADS;
+    static constexpr int X_BYTES = KS * PX * 32;
+    static constexpr int LDS_BYTES = X_BYTES + T * MAXNT * 1024;
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams p)
+{
+    using C = GCfg<KS, S>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xt = smem;
+    char* wt = smem + C::X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // work-group -> (strip of the output row, output row, image), output-channel group
+    const int strips = (p.wo + TPX - 1) / TPX;
+    int b = blockIdx.x;
+    const int strip = b % strips; b /= strips;
+    const int yo = b % p.ho;
+    const int img = b / p.ho;
+    const int xo0 = strip * TPX;
+    const int ct0 = blockIdx.y * MAXNT;
+    const int nt = min(MAXNT, p.ct_total - ct0);
+
+    // per-thread pieces of the input window: pixel index inside the image (or -1), constant over the chunks
+    int xpix[C::NXP];
+    int xhalf[C::NXP];
+#pragma unroll
+    for (int m = 0; m < C::NXP; ++m) {
+        const int q = tid + m * NTHREADS;
+        const int ky = q / (C::PX * 2), rem = q - ky * (C::PX * 2);
+        const int px = rem >> 1;
+        const int yy = yo * S + ky - p.pad, xx = xo0 * S + px - p.pad;
+        const bool ok = q < C::XPIECES && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+        xpix[m] = ok ? (img * p.h + yy) * p.w + xx : -1;
+        xhalf[m] = rem & 1;
+    }
+
+    uint4 xreg[C::NXP], wreg[C::NWP];
+    auto prefetch = [&](const int kc) {
+        // the map that holds input chunk kc, and the chunk's first channel inside it
+        int coff = kc * 16;
+        const char* sp = p.src[0].p;
+        int cstride = p.src[0].cstride;
+        if (p.nsrc > 1 && coff >= p.src[0].c) {
+            coff -= p.src[0].c; sp = p.src[1].p; cstride = p.src[1].cstride;
+            if (p.nsrc > 2 && coff >= p.src[1].c) { coff -= p.src[1].c; sp = p.src[2].p; cstride = p.src[2].cstride; }
+        }
+#pragma unroll
+        for (int m = 0; m < C::NXP; ++m) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (xpix[m] >= 0) v = *(const uint4*)(sp + ((long long)xpix[m] * cstride + coff + xhalf[m] * 8) * 2);
+            xreg[m] = v;
+        }
+#pragma unroll
+        for (int m = 0; m < C::NWP; ++m) {
+            const int q = tid + m * NTHREADS;
+            const int tap = q / (MAXNT * 64), r = q - tap * (MAXNT * 64);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < C::WPIECES && r < nt * 64)
+                v = *(const uint4*)(p.wpack + ((long long)(tap * p.kc_total + kc) * p.ct_total + ct0) * 1024 + r * 16);
+            wreg[m] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int m = 0; m < C::NXP; ++m) {
+            const int q = tid + m * NTHREADS;
+            if (q < C::XPIECES) *(uint4*)(xt + q * 16) = xreg[m];
+        }
+#pragma unroll
+        for (int m = 0; m < C::NWP; ++m) {
+            const int q = tid + m * NTHREADS;
+            if (q < C::WPIECES) *(uint4*)(wt + q * 16) = wreg[m];
+        }
+    };
+
+    f32x16 acc[MAXNT];
+#pragma unroll
+    for (int ct = 0; ct < MAXNT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+
+    const int pl = wave * 32 + (lane & 31);   // this lane's output pixel inside the strip
+    const int hl = lane >> 5;                 // which 8 of the chunk's 16 channels this lane feeds
+
+    prefetch(0);
+    for (int kc = 0; kc < p.kc_total; ++kc) {
+        __syncthreads();   // everyone is done reading the previous chunk
+        commit();
+        __syncthreads();
+        if (kc + 1 < p.kc_total) prefetch(kc + 1);   // in flight during the MFMAs below
+#pragma unroll
+        for (int tap = 0; tap < C::T; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const bf16x8 bfrag = *(const bf16x8*)(xt + ((ky * C::PX + pl * S + kx) * 2 + hl) * 16);
+#pragma unroll
+            for (int ct = 0; ct < MAXNT; ++ct) {
+                if (ct < nt) {
+                    const bf16x8 afrag = *(const bf16x8*)(wt + ((tap * MAXNT + ct) * 64 + lane) * 16);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: accumulator register r of lane l is output channel 32 ct + 8 (r >> 2) + 4 (l >> 5) + (r & 3) of pixel l & 31
+    const int xo = xo0 + pl;
+    if (xo >= p.wo) return;
+    const long long opix = ((long long)img * p.ho + yo) * p.wo + xo;
+    char* dp = p.dst + opix * p.cout_stride * 2;
+    const char* rp = p.res ? p.res + opix * p.cout_stride * 2 : nullptr;
+#pragma unroll
+    for (int ct = 0; ct < MAXNT; ++ct) {
+        if (ct >= nt) break;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = (ct0 + ct) * 32 + 8 * g + 4 * hl;
+            if (c0 >= p.cout_w) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
+                const float t = acc[ct][4 * g + e] + bia;
+                v[e] = fmaxf(t, t * p.slope) * p.alpha;   // act(t) = max(t, slope * t), slope in {1, 0, s}
+            }
+            if (rp != nullptr) {
+                const uint2 r = *(const uint2*)(rp + c0 * 2);
+                v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+            }
+            *(uint2*)(dp + c0 * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    }
+}
+
+// fp32 OIHW (or OI11) master weights -> bf16 MFMA fragment order [tap][16-channel chunk][32-channel tile][lane][8]
+__global__ void gemm_pack_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout, int cin,
+                                         int ks, int kc_total, int ct_total, int total)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    int rest = idx >> 9;
+    const int ct = rest % ct_total; rest /= ct_total;
+    const int kc = rest % kc_total; rest /= kc_total;
+    const int tap = rest;
+    const int ky = tap / ks, kx = tap - ky * ks;
+    const int co = ct * 32 + (lane & 31);
+    const int ci = kc * 16 + 8 * (lane >> 5) + j;
+    float v = 0.0f;
+    if (co < cout && ci < cin) v = w[(((long long)co * cin + ci) * ks + ky) * ks + kx];
+    out[idx] = f32_to_bf16_bits(v);
+}
+
+template <int KS, int S>
+int launch_gemm(const GemmParams& p, hipStream_t stream)
+{
+    using C = GCfg<KS, S>;
+    static std::atomic<bool> configured_dev[kSrhipMaxDevices];
+    const int dev = srhip_current_device();
+    if (!configured_dev[dev].load(std::memory_order_acquire)) {
+        if (C::LDS_BYTES > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)conv_gemm_kernel<KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+            srhip_set_error("conv_gemm: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);
+            return SRHIP_ERR_LAUNCH;
+        }
+        configured_dev[dev].store(true, std::memory_order_release);
+    }
+    const long long blocks = (long long)srhip_div_up(p.wo, TPX) * p.ho * p.n;
+    SRHIP_REQUIRE(blocks < (1ll << 31), "conv_gemm: too many work-groups");
+    hipLaunchKernelGGL((conv_gemm_kernel<KS, S>), dim3((unsigned)blocks, (unsigned)srhip_div_up(p.ct_total, MAXNT)), dim3(NTHREADS),
+                       C::LDS_BYTES, stream, p);
+    return srhip_check_launch("conv_gemm_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+SRHIP_API size_t srhip_conv_gemm_packed_bytes(int cin_padded, int cout, int ksize)
+{
+    if (cin_padded < 16 || cin_padded % 16 || cout < 1 || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)ksize * ksize * (cin_padded / 16) * ((cout + 31) / 32) * 1024;
+}
+
+SRHIP_API int srhip_conv_gemm_pack_weights(const float* weight, void* packed, int cout, int cin, int ksize, int cin_padded,
+                                           void* stream)
+{
+    SRHIP_REQUIRE(weight && packed, "conv_gemm_pack_weights: null pointer");
+    SRHIP_REQUIRE(cout >= 1 && cin >= 1 && (ksize == 1 || ksize == 3), "conv_gemm_pack_weights: bad shape");
+    SRHIP_REQUIRE(cin_padded >= cin && cin_padded % 16 == 0, "conv_gemm_pack_weights: cin_padded must be a multiple of 16 and >= cin");
+    const int kc_total = cin_padded / 16, ct_total = (cout + 31) / 32;
+    const long long total = (long long)ksize * ksize * kc_total * ct_total * 512;
+    SRHIP_REQUIRE(total < (1ll << 31), "conv_gemm_pack_weights: weight too large");
+    hipLaunchKernelGGL(gemm_pack_weights_kernel, dim3(srhip_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       (unsigned short*)packed, cout, cin, ksize, kc_total, ct_total, (int)total);
+    return srhip_check_launch("gemm_pack_weights_kernel");
+}
+
+SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* a, void* stream)
+{
+    SRHIP_REQUIRE(a != nullptr, "conv_gemm: null argument block");
+    SRHIP_REQUIRE(a->nsrc >= 1 && a->nsrc <= 3 && a->wpack && a->dst, "conv_gemm: null pointer or bad source count");
+    SRHIP_REQUIRE(a->n >= 1 && a->h >= 1 && a->w >= 1 && a->cout >= 1, "conv_gemm: empty tensor");
+    SRHIP_REQUIRE((a->ksize == 1 || a->ksize == 3) && (a->stride == 1 || a->stride == 2) && (a->pad == 0 || a->pad == 1) && a->pad <= a->ksize / 2,
+                  "conv_gemm: kernel %d stride %d pad %d not supported (k in {1,3}, s in {1,2}, p in {0,1})", a->ksize, a->stride, a->pad);
+    SRHIP_REQUIRE(a->act == SRHIP_ACT_NONE || a->act == SRHIP_ACT_RELU || a->act == SRHIP_ACT_LRELU, "conv_gemm: bad activation %d", a->act);
+    SRHIP_REQUIRE(a->alpha > 0.0f, "conv_gemm: alpha must be positive");
+    GemmParams p;
+    int cin_pad = 0;
+    for (int k = 0; k < 3; ++k) {
+        p.src[k].p = nullptr; p.src[k].c = 0; p.src[k].cstride = 0;
+        if (k < a->nsrc) {
+            SRHIP_REQUIRE(a->src[k] != nullptr && a->c[k] >= 16 && a->c[k] % 16 == 0 && a->cstride[k] >= a->c[k] && a->cstride[k] % 8 == 0,
+                          "conv_gemm: source %d: channels %d (multiple of 16) of a tensor with %d per pixel (multiple of 8)", k, a->c[k], a->cstride[k]);
+            SRHIP_REQUIRE((size_t)a->src[k] % 16 == 0, "conv_gemm: source %d is not 16-byte aligned", k);
+            SRHIP_REQUIRE((long long)a->n * a->h * a->w < (1ll << 31), "conv_gemm: too many pixels for 32-bit indices");
+            p.src[k].p = (const char*)a->src[k]; p.src[k].c = a->c[k]; p.src[k].cstride = a->cstride[k];
+            cin_pad += a->c[k];
+        }
+    }
+    p.nsrc = a->nsrc;
+    p.wpack = (const char*)a->wpack; p.bias = a->bias; p.res = (const char*)a->res; p.dst = (char*)a->dst;
+    p.n = a->n; p.h = a->h; p.w = a->w;
+    p.ho = (a->h + 2 * a->pad - a->ksize) / a->stride + 1;
+    p.wo = (a->w + 2 * a->pad - a->ksize) / a->stride + 1;
+    SRHIP_REQUIRE(p.ho >= 1 && p.wo >= 1, "conv_gemm: the kernel does not fit the image");
+    p.kc_total = cin_pad / 16;
+    p.ct_total = (a->cout + 31) / 32;
+    p.cout = a->cout;
+    p.cout_w = (a->cout + 15) / 16 * 16;
+    p.cout_stride = a->cout_stride;
+    SRHIP_REQUIRE(a->cout_stride >= p.cout_w && a->cout_stride % 4 == 0, "conv_gemm: cout_stride %d must hold pad16(cout) = %d channels", a->cout_stride, p.cout_w);
+    SRHIP_REQUIRE((size_t)a->dst % 8 == 0 && (a->res == nullptr || (size_t)a->res % 8 == 0), "conv_gemm: dst / res must be 8-byte aligned");
+    p.pad = a->pad;
+    p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
+    p.alpha = a->alpha;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->ksize == 3 && a->stride == 1) return launch_gemm<3, 1>(p, s);
+    if (a->ksize == 3 && a->stride == 2) return launch_gemm<3, 2>(p, s);
+    if (a->ksize == 1 && a->stride == 1) return launch_gemm<1, 1>(p, s);
+    return launch_gemm<1, 2>(p, s);
+}
+
+}  // extern "C"

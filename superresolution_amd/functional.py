@@ -6,9 +6,11 @@ own device memory and to name the current HIP stream.  NHWC tensors are plain co
 """
 from typing import Optional
 
+import os
+
 import torch
 
-from ._lib import Conv3x3Args, Conv3x3PairArgs, check, lib
+from ._lib import ConvGemmArgs, Conv3x3Args, Conv3x3PairArgs, check, lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 RES_ADD, RES_MASK, RES_PRE = 0, 1, 2
@@ -322,6 +324,9 @@ def gradient_map(x: torch.Tensor, eps: float = 1e-6, out: Optional[torch.Tensor]
 
 
 _pack_cache = {}
+# SRHIP_NO_CONV_GEMM=1 sends the layers outside the 3x3 kernel's native shape down the older path (64-channel 3x3 launches
+# chained through bf16 partial sums); kept for A/B timing
+use_conv_gemm = os.environ.get("SRHIP_NO_CONV_GEMM", "0") != "1"
 
 
 def _cached_pack(weight: torch.Tensor, tag, build) -> torch.Tensor:
@@ -355,8 +360,10 @@ def _k_slices(cpad: int):
 def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 1,
                 act: int = ACT_NONE, slope: float = 0.0, res: Optional[torch.Tensor] = None,
                 alpha: float = 1.0) -> torch.Tensor:
-    """alpha * act(nn.Conv2d(x)) + res on an NHWC bf16 tensor with any channel count, on the MFMA kernel
-    wherever the layer can be written as 3x3 / stride 1 / pad 1 launches:
+    """alpha * act(nn.Conv2d(x)) + res on an NHWC bf16 tensor with any channel count.  A 3x3 / stride 1 / pad 1 layer with
+    at most 64 input and output channels is one launch of the register-resident MFMA kernel; every other layer with kernel 1
+    or 3, stride 1 or 2, padding 0 or 1 is ONE launch of the implicit-GEMM kernel (``conv_gemm``: fp32 accumulation over the
+    whole reduction, concatenated sources read in place).  The older composition below remains for A/B timing:
 
     * more than 64 input channels: one launch per 64-channel slice (read in place), the partial sums accumulated in
       place through the residual input (pre-activation form; partial sums are rounded to bf16 between launches);
@@ -379,6 +386,12 @@ def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: i
     cpad = sum(t.shape[-1] for t in srcs)
     as3x3 = (kh, kw, padding) == (3, 3, 1) and stride in (1, 2)
     as1x1 = (kh, kw, padding, stride) == (1, 1, 0, 1)
+    gemm_ok = use_conv_gemm and kh == kw and kh in (1, 3) and stride in (1, 2) and padding in (0, 1) and padding <= kh // 2 \
+        and alpha > 0.0 and len(srcs) <= 3 and all(t.shape[-1] % 16 == 0 for t in srcs)
+    if gemm_ok and not (as3x3 and stride == 1 and len(srcs) == 1 and cpad <= 64 and cout <= 64):
+        wp = _cached_pack(weight, ("gemm", cpad), lambda: conv_gemm_pack_weights(weight.detach().float().contiguous(), cpad))
+        return conv_gemm(tuple(srcs), wp, None if bias is None else bias.detach(), cout, kh, stride=stride, padding=padding,
+                         act=act, slope=slope, alpha=alpha, res=res)
     if not (as3x3 or as1x1) or (alpha != 1.0 and (cpad > 64 or cout > 64 or stride != 1)):
         xin = srcs[0]
         for t in srcs[1:]:
@@ -427,6 +440,59 @@ def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: i
         out = max_pool2d_nhwc(out, 1, 2)  # out[i, j] = stride-1 result at (2i, 2j)
     if res is not None and not fuse_res:
         out = add_bf16(out, res)
+    return out
+
+
+def conv_gemm_pack_weights(weight: torch.Tensor, cin_padded: int) -> torch.Tensor:
+    """fp32 (O, I, k, k) master weights, k in {1, 3} -> packed bf16 fragments of the implicit-GEMM convolution."""
+    weight = _req(weight, torch.float32, "weight")
+    cout, cin, kh, kw = weight.shape
+    if kh != kw or kh not in (1, 3):
+        raise ValueError("conv_gemm_pack_weights: kernel must be 1x1 or 3x3")
+    nbytes = lib.srhip_conv_gemm_packed_bytes(cin_padded, cout, kh)
+    if nbytes == 0 or cin_padded < cin:
+        raise ValueError("conv_gemm_pack_weights: cin_padded must be a multiple of 16 and >= the weight's input channels")
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+    check(lib.srhip_conv_gemm_pack_weights(weight.data_ptr(), packed.data_ptr(), cout, cin, kh, cin_padded, _stream()))
+    return packed
+
+
+def conv_gemm(srcs, wpack: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ksize: int, stride: int = 1, padding: int = 0,
+              act: int = ACT_NONE, slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """alpha * act(conv_{k, stride, padding}(concat(srcs)) + bias) + res in ONE launch with fp32 accumulation over the whole
+    reduction.  ``srcs``: one NHWC bf16 map or a tuple of up to three with equal (N,H,W), each a multiple of 16 channels wide
+    (a source may be ``(tensor, first_channel, channels)`` to read a channel slice in place)."""
+    srcs = list(srcs) if isinstance(srcs, (tuple, list)) and not (len(srcs) == 3 and isinstance(srcs[1], int)) else [srcs]
+    if not 1 <= len(srcs) <= 3:
+        raise ValueError("conv_gemm: one to three sources")
+    a = ConvGemmArgs()
+    shape = None
+    for k, s_ in enumerate(srcs):
+        t, off, c = s_ if isinstance(s_, tuple) else (s_, 0, s_.shape[-1])
+        t = _req(t, torch.bfloat16, f"src[{k}]")
+        if shape is None:
+            shape = tuple(t.shape[:3])
+        if tuple(t.shape[:3]) != shape or c % 16 or off % 8 or off < 0 or off + c > t.shape[-1]:
+            raise ValueError("conv_gemm: sources must share (N,H,W); channel windows are multiples of 16 at offsets that are multiples of 8")
+        a.src[k], a.c[k], a.cstride[k] = t.data_ptr() + 2 * off, c, t.shape[-1]
+    a.nsrc = len(srcs)
+    n, h, w = shape
+    ho, wo = (h + 2 * padding - ksize) // stride + 1, (w + 2 * padding - ksize) // stride + 1
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias")
+    if out is None:
+        out = torch.empty((n, ho, wo, pad16(cout)), dtype=torch.bfloat16, device=wpack.device)
+    elif out.dtype != torch.bfloat16 or not out.is_contiguous() or tuple(out.shape[:3]) != (n, ho, wo) or out.shape[3] < pad16(cout):
+        raise ValueError("conv_gemm: `out` must be a contiguous NHWC bf16 tensor of the output size with at least pad16(cout) channels")
+    if res is not None:
+        res = _req(res, torch.bfloat16, "res")
+        if res.shape != out.shape:
+            raise ValueError("conv_gemm: residual shape must equal the output shape")
+    a.wpack, a.bias, a.res, a.dst = wpack.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr()
+    a.n, a.h, a.w, a.cout, a.cout_stride = n, h, w, cout, out.shape[3]
+    a.ksize, a.stride, a.pad, a.act, a.slope, a.alpha = ksize, stride, padding, act, slope, alpha
+    check(lib.srhip_conv_gemm_fwd(a, _stream()))
     return out
 
 
