@@ -27,13 +27,15 @@
 namespace {
 
 constexpr int TPX = 128;    // output pixels per work-group
-constexpr int MAXNT = 4;    // 32-channel output tiles per work-group
+constexpr int MAXNT = 6;    // most 32-channel output tiles per work-group (a template parameter of the kernel)
 constexpr int NTHREADS = 256;
+constexpr unsigned kOobOff = 0x80000000u;   // buffer offset that fails the bounds check: the load returns zeros
 
 struct GemmSrc {
     const char* p;
     int c;         // channels read from this map (multiple of 16)
     int cstride;   // channels per pixel of the tensor it lives in
+    unsigned bytes;   // size of the tensor (< 2^31)
 };
 
 struct GemmParams {
@@ -48,24 +50,67 @@ struct GemmParams {
     int cout, cout_w, cout_stride;
     int pad;
     float slope, alpha;
+    unsigned wbytes;   // size of the packed weights
 };
 
-template <int KS, int S>
+template <int KS, int S, int NT>
 struct GCfg {
     static constexpr int T = KS * KS;
+    static constexpr int KSUB = KS == 1 ? 4 : 1;                    // 16-channel chunks per LDS stage (1x1 layers: 64 channels)
+    static constexpr int NSTEP = T * KSUB;                          // (chunk, tap) steps per stage, NT MFMAs each
     static constexpr int PX = (TPX - 1) * S + KS;                   // input pixels per staged row
-    static constexpr int XPIECES = KS * PX * 2;                     // 16-byte pieces of the input window
-    static constexpr int NXP = (XPIECES + NTHREADS - 1) / NTHREADS; // per thread
-    static constexpr int WPIECES = T * MAXNT * 64;
+    static constexpr int XP1 = KS * PX * 2;                         // 16-byte pieces of the input window of ONE chunk
+    static constexpr int NXP1 = (XP1 + NTHREADS - 1) / NTHREADS;    // per thread and chunk
+    static constexpr int NXP = NXP1 * KSUB;
+    static constexpr int WPIECES = NSTEP * NT * 64;
     static constexpr int NWP = (WPIECES + NTHREADS - 1) / NTHREADS;
-    static constexpr int X_BYTES = KS * PX * 32;
-    static constexpr int LDS_BYTES = X_BYTES + T * MAXNT * 1024;
+    static constexpr int X_BYTES = KSUB * KS * PX * 32;             // [row][chunk][pixel][32 B]
+    static constexpr int LDS_BYTES = X_BYTES + NSTEP * NT * 1024;   // + [chunk][tap][tile][1 KiB]
+    static_assert(NSTEP * NT * 1024 < 65536, "weight fragments are addressed by the LDS instruction's 16-bit offset");
 };
 
-template <int KS, int S>
+// loops whose index must be a compile-time constant from the start (register arrays stay registers)
+template <int V>
+struct GInt { static constexpr int value = V; };
+template <int B, int E, class F>
+__device__ __forceinline__ void g_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(GInt<B>{});
+        g_for<B + 1, E>(f);
+    }
+}
+
+// LDS fragment read with an immediate offset, as asm: the waits of the MFMA section are counted by hand (the compiler
+// keeps only one or two reads in flight ahead of each MFMA, far less than the LDS latency)
+template <int OFF>
+__device__ __forceinline__ bf16x8 g_lds_read(unsigned addr)
+{
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void g_lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 gemm_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int KS, int S, int NT>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams p)
 {
-    using C = GCfg<KS, S>;
+    using C = GCfg<KS, S, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xt = smem;
     char* wt = smem + C::X_BYTES;
@@ -78,89 +123,139 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     const int yo = b % p.ho;
     const int img = b / p.ho;
     const int xo0 = strip * TPX;
-    const int ct0 = blockIdx.y * MAXNT;
-    const int nt = min(MAXNT, p.ct_total - ct0);
+    const int ct0 = blockIdx.y * NT;
+    const int nt = min(NT, p.ct_total - ct0);   // < NT only in the last group: its missing tiles read zero weights
 
-    // per-thread pieces of the input window: pixel index inside the image (or -1), constant over the chunks
-    int xpix[C::NXP];
-    int xhalf[C::NXP];
-#pragma unroll
-    for (int m = 0; m < C::NXP; ++m) {
+    // All global loads are buffer loads whose out-of-image / out-of-range pieces carry an offset that fails the bounds
+    // check and come back as zeros: no branches in the load phase.
+    // per-thread pieces of the input window: pixel index inside the image, constant over the chunks
+    // (the same table serves every chunk of a stage: piece m of chunk `sub` is register m + sub * NXP1)
+    int xpix[C::NXP1];
+    unsigned xhalf[C::NXP1], xlds[C::NXP1];
+    g_for<0, C::NXP1>([&](auto m_c) {
+        constexpr int m = decltype(m_c)::value;
         const int q = tid + m * NTHREADS;
         const int ky = q / (C::PX * 2), rem = q - ky * (C::PX * 2);
         const int px = rem >> 1;
         const int yy = yo * S + ky - p.pad, xx = xo0 * S + px - p.pad;
-        const bool ok = q < C::XPIECES && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
+        const bool ok = (q < C::XP1) & (yy >= 0) & (yy < p.h) & (xx >= 0) & (xx < p.w);
         xpix[m] = ok ? (img * p.h + yy) * p.w + xx : -1;
-        xhalf[m] = rem & 1;
-    }
+        xhalf[m] = (unsigned)(rem & 1) * 16u;
+        xlds[m] = (unsigned)((ky * C::KSUB * C::PX + px) * 32 + (rem & 1) * 16);   // + sub * PX * 32
+    });
+    // per-thread pieces of the weight tile: offset inside one (tap, chunk) block of ct_total KiB, plus the tap's stride
+    unsigned woff[C::NWP];
+    int wsub[C::NWP];
+    g_for<0, C::NWP>([&](auto m_c) {
+        constexpr int m = decltype(m_c)::value;
+        const int q = tid + m * NTHREADS;
+        const int step = q / (NT * 64), r = q - step * (NT * 64);
+        const int sub = step / C::T, tap = step - sub * C::T;
+        const bool ok = (q < C::WPIECES) & (r < nt * 64);
+        woff[m] = ok ? (unsigned)(((tap * p.kc_total + sub) * p.ct_total + ct0) * 1024 + r * 16) : kOobOff;
+        wsub[m] = sub;
+    });
+    const __amdgpu_buffer_rsrc_t wsrd = gemm_rsrc(p.wpack, p.wbytes);
+    const __amdgpu_buffer_rsrc_t xsrd0 = gemm_rsrc(p.src[0].p, p.src[0].bytes);
+    const __amdgpu_buffer_rsrc_t xsrd1 = gemm_rsrc(p.nsrc > 1 ? p.src[1].p : p.src[0].p, p.nsrc > 1 ? p.src[1].bytes : 0u);
+    const __amdgpu_buffer_rsrc_t xsrd2 = gemm_rsrc(p.nsrc > 2 ? p.src[2].p : p.src[0].p, p.nsrc > 2 ? p.src[2].bytes : 0u);
 
+    // scalars of the argument block that the chunk loop needs (plain locals: the block itself is never indexed there)
+    const int nsrc = p.nsrc, sc0 = p.src[0].c, sc1 = p.src[1].c;
+    const int st0 = p.src[0].cstride, st1 = p.src[1].cstride, st2 = p.src[2].cstride;
+    const int kc_total = p.kc_total, ct_total = p.ct_total;
     uint4 xreg[C::NXP], wreg[C::NWP];
-    auto prefetch = [&](const int kc) {
-        // the map that holds input chunk kc, and the chunk's first channel inside it
-        int coff = kc * 16;
-        const char* sp = p.src[0].p;
-        int cstride = p.src[0].cstride;
-        if (p.nsrc > 1 && coff >= p.src[0].c) {
-            coff -= p.src[0].c; sp = p.src[1].p; cstride = p.src[1].cstride;
-            if (p.nsrc > 2 && coff >= p.src[1].c) { coff -= p.src[1].c; sp = p.src[2].p; cstride = p.src[2].cstride; }
-        }
-#pragma unroll
-        for (int m = 0; m < C::NXP; ++m) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (xpix[m] >= 0) v = *(const uint4*)(sp + ((long long)xpix[m] * cstride + coff + xhalf[m] * 8) * 2);
-            xreg[m] = v;
-        }
-#pragma unroll
-        for (int m = 0; m < C::NWP; ++m) {
-            const int q = tid + m * NTHREADS;
-            const int tap = q / (MAXNT * 64), r = q - tap * (MAXNT * 64);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q < C::WPIECES && r < nt * 64)
-                v = *(const uint4*)(p.wpack + ((long long)(tap * p.kc_total + kc) * p.ct_total + ct0) * 1024 + r * 16);
-            wreg[m] = v;
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int m = 0; m < C::NXP; ++m) {
-            const int q = tid + m * NTHREADS;
-            if (q < C::XPIECES) *(uint4*)(xt + q * 16) = xreg[m];
-        }
-#pragma unroll
-        for (int m = 0; m < C::NWP; ++m) {
-            const int q = tid + m * NTHREADS;
-            if (q < C::WPIECES) *(uint4*)(wt + q * 16) = wreg[m];
-        }
-    };
 
-    f32x16 acc[MAXNT];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int ct = 0; ct < MAXNT; ++ct)
+    for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
 
     const int pl = wave * 32 + (lane & 31);   // this lane's output pixel inside the strip
     const int hl = lane >> 5;                 // which 8 of the chunk's 16 channels this lane feeds
 
-    prefetch(0);
-    for (int kc = 0; kc < p.kc_total; ++kc) {
-        __syncthreads();   // everyone is done reading the previous chunk
-        commit();
-        __syncthreads();
-        if (kc + 1 < p.kc_total) prefetch(kc + 1);   // in flight during the MFMAs below
-#pragma unroll
-        for (int tap = 0; tap < C::T; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const bf16x8 bfrag = *(const bf16x8*)(xt + ((ky * C::PX + pl * S + kx) * 2 + hl) * 16);
-#pragma unroll
-            for (int ct = 0; ct < MAXNT; ++ct) {
-                if (ct < nt) {
-                    const bf16x8 afrag = *(const bf16x8*)(wt + ((tap * MAXNT + ct) * 64 + lane) * 16);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[ct], 0, 0, 0);
-                }
-            }
+    // Iteration st (a stage = KSUB chunks): [commit stage st to LDS] -> issue the global loads of stage st + 1 -> MFMAs
+    // of stage st.  Iteration -1 only issues the loads of stage 0.  (Load and commit code exist once, inline: as lambdas
+    // called from two places the compiler indexed their closure dynamically and every register array behind it moved to
+    // scratch.)
+    const int nstage = (kc_total + C::KSUB - 1) / C::KSUB;
+    const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)((pl * S * 2 + hl) * 16);
+    const unsigned aaddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(C::X_BYTES + lane * 16);
+    for (int st = -1; st < nstage; ++st) {
+        if (st >= 0) {
+            __syncthreads();   // everyone is done reading the previous stage
+            g_for<0, C::NXP>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                constexpr int sub = m / C::NXP1, m1 = m % C::NXP1;
+                const int q = tid + m1 * NTHREADS;
+                if (C::XP1 % NTHREADS == 0 || q < C::XP1) *(uint4*)(xt + xlds[m1] + sub * C::PX * 32) = xreg[m];
+            });
+            g_for<0, C::NWP>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                const int q = tid + m * NTHREADS;
+                if (C::WPIECES % NTHREADS == 0 || q < C::WPIECES) *(uint4*)(wt + q * 16) = wreg[m];
+            });
+            __syncthreads();
         }
+        {
+            // the last iteration repeats its own stage: harmless, and it keeps the code free of a branch around the loads
+            const int ns = st + 1 < nstage ? st + 1 : st;
+            g_for<0, C::KSUB>([&](auto s_c) {
+                constexpr int sub = decltype(s_c)::value;
+                // the map that holds input chunk kc, and the chunk's first channel inside it
+                const int kc = ns * C::KSUB + sub;
+                int coff = kc * 16;
+                int cstride = st0;
+                __amdgpu_buffer_rsrc_t xs = xsrd0;
+                if (nsrc > 1 && coff >= sc0) {
+                    coff -= sc0; cstride = st1; xs = xsrd1;
+                    if (nsrc > 2 && coff >= sc1) { coff -= sc1; cstride = st2; xs = xsrd2; }
+                }
+                const bool live = kc < kc_total;   // a stage may reach past the last chunk: zeros
+                const unsigned cbytes = (unsigned)cstride * 2u, soff = (unsigned)coff * 2u;
+                g_for<0, C::NXP1>([&](auto m_c) {
+                    constexpr int m = decltype(m_c)::value;
+                    xreg[sub * C::NXP1 + m] = gemm_load16(xs, (live && xpix[m] >= 0) ? (unsigned)xpix[m] * cbytes + xhalf[m] : kOobOff, soff);
+                });
+            });
+            const unsigned wsoff = (unsigned)(ns * C::KSUB * ct_total) * 1024u;
+            g_for<0, C::NWP>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                const bool live = C::KSUB == 1 || ns * C::KSUB + wsub[m] < kc_total;
+                wreg[m] = gemm_load16(wsrd, live ? woff[m] : kOobOff, wsoff);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the loads above stay in front of the MFMA section
+        if (st < 0) continue;
+        // NSTEP steps of (1 pixel fragment + NT weight fragments -> NT MFMAs); the fragments of step i + 1 are requested
+        // before the MFMAs of step i, with counted waits
+        bf16x8 af[2][NT], bq[2];
+        g_for<0, C::NSTEP>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            auto issue = [&](auto j_c) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_c)::value;
+                constexpr int sub = j / C::T, tap = j % C::T, ky = tap / KS, kx = tap % KS;
+                bq[j & 1] = g_lds_read<((ky * C::KSUB + sub) * C::PX + kx) * 32>(baddr);
+                g_for<0, NT>([&](auto ct_c) {
+                    constexpr int ct = decltype(ct_c)::value;
+                    af[j & 1][ct] = g_lds_read<(j * NT + ct) * 1024>(aaddr);
+                });
+            };
+            if constexpr (i == 0) issue(GInt<0>{});
+            if constexpr (i + 1 < C::NSTEP) {
+                issue(GInt<i + 1>{});
+                g_lds_wait<NT + 1>();
+            } else {
+                g_lds_wait<0>();   // nothing stays in flight across the barrier
+            }
+            SRHIP_LOAD_FENCE(bq[i & 1]);
+            g_for<0, NT>([&](auto ct_c) {
+                constexpr int ct = decltype(ct_c)::value;
+                SRHIP_LOAD_FENCE(af[i & 1][ct]);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1], acc[ct], 0, 0, 0);
+            });
+        });
     }
 
     // epilogue: accumulator register r of lane l is output channel 32 ct + 8 (r >> 2) + 4 (l >> 5) + (r & 3) of pixel l & 31
@@ -170,8 +265,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     char* dp = p.dst + opix * p.cout_stride * 2;
     const char* rp = p.res ? p.res + opix * p.cout_stride * 2 : nullptr;
 #pragma unroll
-    for (int ct = 0; ct < MAXNT; ++ct) {
-        if (ct >= nt) break;
+    for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = (ct0 + ct) * 32 + 8 * g + 4 * hl;
@@ -212,15 +306,15 @@ __global__ void gemm_pack_weights_kernel(const float* __restrict__ w, unsigned s
     out[idx] = f32_to_bf16_bits(v);
 }
 
-template <int KS, int S>
-int launch_gemm(const GemmParams& p, hipStream_t stream)
+template <int KS, int S, int NT>
+int launch_gemm_nt(const GemmParams& p, int groups, hipStream_t stream)
 {
-    using C = GCfg<KS, S>;
+    using C = GCfg<KS, S, NT>;
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];
     const int dev = srhip_current_device();
     if (!configured_dev[dev].load(std::memory_order_acquire)) {
         if (C::LDS_BYTES > 48 * 1024 &&
-            hipFuncSetAttribute((const void*)conv_gemm_kernel<KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+            hipFuncSetAttribute((const void*)conv_gemm_kernel<KS, S, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
             srhip_set_error("conv_gemm: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);
             return SRHIP_ERR_LAUNCH;
         }
@@ -228,9 +322,26 @@ int launch_gemm(const GemmParams& p, hipStream_t stream)
     }
     const long long blocks = (long long)srhip_div_up(p.wo, TPX) * p.ho * p.n;
     SRHIP_REQUIRE(blocks < (1ll << 31), "conv_gemm: too many work-groups");
-    hipLaunchKernelGGL((conv_gemm_kernel<KS, S>), dim3((unsigned)blocks, (unsigned)srhip_div_up(p.ct_total, MAXNT)), dim3(NTHREADS),
-                       C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<KS, S, NT>), dim3((unsigned)blocks, (unsigned)groups), dim3(NTHREADS), C::LDS_BYTES, stream, p);
     return srhip_check_launch("conv_gemm_kernel");
+}
+
+// Output tiles are spread evenly over the fewest groups of at most MAXNT tiles (5 tiles -> one group of 5, 8 -> two of 4,
+// 7 -> 4 + 3: the last group's missing tile multiplies zero weights and stores nothing).
+template <int KS, int S>
+int launch_gemm(const GemmParams& p, hipStream_t stream)
+{
+    const int maxnt = S == 2 ? 4 : MAXNT;   // the stride-2 window needs more staging registers: 4 tiles fit without spills
+    const int groups = srhip_div_up(p.ct_total, maxnt);
+    const int nt = srhip_div_up(p.ct_total, groups);
+    switch (nt) {
+    case 1: return launch_gemm_nt<KS, S, 1>(p, groups, stream);
+    case 2: return launch_gemm_nt<KS, S, 2>(p, groups, stream);
+    case 3: return launch_gemm_nt<KS, S, 3>(p, groups, stream);
+    case 4: return launch_gemm_nt<KS, S, 4>(p, groups, stream);
+    case 5: return launch_gemm_nt<KS, S, 5>(p, groups, stream);
+    default: return launch_gemm_nt<KS, S, 6>(p, groups, stream);
+    }
 }
 
 }  // namespace
@@ -269,13 +380,16 @@ SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* a, void* stream)
     GemmParams p;
     int cin_pad = 0;
     for (int k = 0; k < 3; ++k) {
-        p.src[k].p = nullptr; p.src[k].c = 0; p.src[k].cstride = 0;
+        p.src[k].p = nullptr; p.src[k].c = 0; p.src[k].cstride = 0; p.src[k].bytes = 0;
         if (k < a->nsrc) {
             SRHIP_REQUIRE(a->src[k] != nullptr && a->c[k] >= 16 && a->c[k] % 16 == 0 && a->cstride[k] >= a->c[k] && a->cstride[k] % 8 == 0,
                           "conv_gemm: source %d: channels %d (multiple of 16) of a tensor with %d per pixel (multiple of 8)", k, a->c[k], a->cstride[k]);
             SRHIP_REQUIRE((size_t)a->src[k] % 16 == 0, "conv_gemm: source %d is not 16-byte aligned", k);
             SRHIP_REQUIRE((long long)a->n * a->h * a->w < (1ll << 31), "conv_gemm: too many pixels for 32-bit indices");
             p.src[k].p = (const char*)a->src[k]; p.src[k].c = a->c[k]; p.src[k].cstride = a->cstride[k];
+            const long long bytes = (long long)a->n * a->h * a->w * a->cstride[k] * 2;
+            SRHIP_REQUIRE(bytes < (1ll << 31), "conv_gemm: source %d larger than 2 GiB", k);
+            p.src[k].bytes = (unsigned)bytes;
             cin_pad += a->c[k];
         }
     }
@@ -295,6 +409,11 @@ SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* a, void* stream)
     p.pad = a->pad;
     p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
     p.alpha = a->alpha;
+    {
+        const size_t wb = srhip_conv_gemm_packed_bytes(cin_pad, a->cout, a->ksize);
+        SRHIP_REQUIRE(wb > 0 && wb < (1ull << 31), "conv_gemm: packed weights too large");
+        p.wbytes = (unsigned)wb;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (a->ksize == 3 && a->stride == 1) return launch_gemm<3, 1>(p, s);
     if (a->ksize == 3 && a->stride == 2) return launch_gemm<3, 2>(p, s);

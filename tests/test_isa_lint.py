@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINT = os.path.join(ROOT, "tools", "isa_lint.py")
-KERNELS = ["conv3x3_mfma.hip", "conv3x3_wgrad.hip"]
+KERNELS = ["conv3x3_mfma.hip", "conv3x3_wgrad.hip", "conv3x3_pair.hip", "conv_gemm.hip"]
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
