@@ -9,25 +9,34 @@
 // NHWC bf16 activations, fp32 accumulation over the WHOLE reduction (all taps, all input channels of all sources) in
 // one launch: no partial sums leave the registers.  k in {1, 3}, s in {1, 2}, p in {0, 1}.
 //
-//   * A work-group (4 waves) computes 128 pixels of one output row x up to 128 output channels (4 MFMA tiles of 32);
-//     wave w owns pixels 32w .. 32w+31 for all of them: 4 accumulators of 16 registers.
-//   * The reduction runs over 16-channel chunks of the concatenated input.  Per chunk the work-group stages in LDS
-//     the input window (k rows x ((128-1)s + k) pixels x 32 B; rows and columns outside the image as zeros) and the
-//     chunk's weights for all k*k taps (k*k x 4 fragments of 1 KiB, already in MFMA operand order), then every wave
-//     issues k*k x 4 MFMAs from ds_read_b128 fragments.  The next chunk's global loads are issued before the MFMAs of
-//     the current one and held in registers, so HBM/L2 latency hides behind the matrix work.
+//   * A work-group (4 waves, two work-groups per CU) computes 2 output rows x 128 pixels x up to 96 output channels
+//     (NT <= 3 MFMA tiles of 32; wider layers run as channel groups).  Wave w owns row w / 2, pixels 64 (w % 2) .. + 63 as
+//     two MFMA pixel tiles: 2 x NT accumulators of 16 registers, and every weight fragment read from LDS feeds two MFMAs.
+//   * The reduction runs over stages of 16 input channels of the concatenated input (64 for 1x1 layers).  Per stage the
+//     work-group stages in LDS the input window (((2-1)s + k) rows x ((128-1)s + k) pixels, rows and columns outside the
+//     image as zeros: buffer loads whose offset fails the bounds check) and the stage's weights for all k*k taps (1 KiB
+//     fragments already in MFMA operand order), then every wave runs k*k steps of (2 + NT fragment reads -> 2 NT MFMAs),
+//     the reads of step i + 1 requested before the MFMAs of step i with counted waits.  The next stage's global loads are
+//     issued in front of the MFMA section and held in registers, so L2 latency overlaps the matrix work; the second
+//     work-group of the CU covers the commit phase and the barriers.
+//   * LDS image of the window: [row][chunk][plane][slot][16 B], plane = which 8 of the 16 channels (x pixel parity for
+//     stride 2): each half-wave's fragment read is 512 contiguous bytes, free of bank conflicts.
+//   * Work-groups walk XCD bands (unit = (g % 8) * ceil(units / 8) + g / 8, channel group fastest): input rows shared by
+//     neighbouring output rows and by a tile's channel groups hit in the XCD's own L2.
 //   * The concatenation of up to three maps (skip connections, model_final.py:375-379) is read in place: a chunk
 //     comes from the map that holds it.
 //   * Epilogue straight from the accumulators: lane (pixel, 4 consecutive channels) -> bias, activation, alpha,
 //     residual, bf16 pack, one 8-byte store.
+// -DGEMM_EXP=1|2|3 builds timing-only variants (no weight / input / any global loads after the first stage).
 #include <atomic>
 
 #include "srhip_common.h"
 
 namespace {
 
-constexpr int TPX = 128;    // output pixels per work-group
-constexpr int MAXNT = 6;    // most 32-channel output tiles per work-group (a template parameter of the kernel)
+constexpr int TPX = 128;    // output pixels per row of a work-group's tile
+constexpr int ROWS = 2;     // output rows per work-group
+constexpr int MAXNT = 3;    // most 32-channel output tiles per work-group (a template parameter of the kernel)
 constexpr int NTHREADS = 256;
 constexpr unsigned kOobOff = 0x80000000u;   // buffer offset that fails the bounds check: the load returns zeros
 
@@ -51,6 +60,8 @@ struct GemmParams {
     int pad;
     float slope, alpha;
     unsigned wbytes;   // size of the packed weights
+    unsigned units;    // work-groups that have work
+    int groups;        // output-channel groups of NT tiles
 };
 
 template <int KS, int S, int NT>
@@ -59,12 +70,20 @@ struct GCfg {
     static constexpr int KSUB = KS == 1 ? 4 : 1;                    // 16-channel chunks per LDS stage (1x1 layers: 64 channels)
     static constexpr int NSTEP = T * KSUB;                          // (chunk, tap) steps per stage, NT MFMAs each
     static constexpr int PX = (TPX - 1) * S + KS;                   // input pixels per staged row
-    static constexpr int XP1 = KS * PX * 2;                         // 16-byte pieces of the input window of ONE chunk
+    static constexpr int KR = (ROWS - 1) * S + KS;                  // staged input rows
+    static constexpr int XP1 = KR * PX * 2;                         // 16-byte pieces of the input window of ONE chunk
     static constexpr int NXP1 = (XP1 + NTHREADS - 1) / NTHREADS;    // per thread and chunk
     static constexpr int NXP = NXP1 * KSUB;
     static constexpr int WPIECES = NSTEP * NT * 64;
     static constexpr int NWP = (WPIECES + NTHREADS - 1) / NTHREADS;
-    static constexpr int X_BYTES = KSUB * KS * PX * 32;             // [row][chunk][pixel][32 B]
+    // LDS image of the input window: [row][chunk][plane][slot][16 B].  A lane's fragment is the 16 bytes (8 channels) of
+    // one pixel; lanes 0..31 of a wave read 32 consecutive output pixels, lanes 32..63 the other 8 channels of the same
+    // pixels.  plane = which 8 channels (x pixel parity for stride 2), slot = pixel (pixel / 2 for stride 2), so each
+    // half-wave reads 512 contiguous bytes: no bank conflicts (with pixel-major 32-byte cells every read was 2-way, for
+    // stride 2 4-way, conflicted: 86 % of the LDS cycles of the first version).
+    static constexpr int NPL = 2 * S;
+    static constexpr int PSL = (PX + S - 1) / S;
+    static constexpr int X_BYTES = KSUB * KR * NPL * PSL * 16;
     static constexpr int LDS_BYTES = X_BYTES + NSTEP * NT * 1024;   // + [chunk][tap][tile][1 KiB]
     static_assert(NSTEP * NT * 1024 < 65536, "weight fragments are addressed by the LDS instruction's 16-bit offset");
 };
@@ -116,14 +135,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     char* wt = smem + C::X_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // work-group -> (strip of the output row, output row, image), output-channel group
-    const int strips = (p.wo + TPX - 1) / TPX;
-    int b = blockIdx.x;
+    // work-group -> unit = (output-channel group, strip of the output rows, pair of output rows, image), group fastest.
+    // Units are walked in XCD bands: the dispatcher deals consecutive work-groups round-robin to the 8 XCDs (one L2
+    // each), so work-group g takes unit (g % 8) * ceil(units / 8) + g / 8 and every XCD owns a contiguous band of rows:
+    // the input rows that neighbouring output rows share, and the re-read of a tile's input by its channel groups, hit in
+    // that XCD's L2 (with the natural order a 167 MB input was fetched as 506 MB and the loads' latency showed).
+    const int strips = (p.wo + TPX - 1) / TPX, rowpairs = (p.ho + ROWS - 1) / ROWS;
+    const unsigned per = (p.units + 7u) >> 3;
+    const unsigned unit = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (unit >= p.units) return;
+    int b = (int)unit;
+    const int grp = b % p.groups; b /= p.groups;
     const int strip = b % strips; b /= strips;
-    const int yo = b % p.ho;
-    const int img = b / p.ho;
+    const int yo = (b % rowpairs) * ROWS;
+    const int img = b / rowpairs;
     const int xo0 = strip * TPX;
-    const int ct0 = blockIdx.y * NT;
+    const int ct0 = grp * NT;
     const int nt = min(NT, p.ct_total - ct0);   // < NT only in the last group: its missing tiles read zero weights
 
     // All global loads are buffer loads whose out-of-image / out-of-range pieces carry an offset that fails the bounds
@@ -141,7 +168,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
         const bool ok = (q < C::XP1) & (yy >= 0) & (yy < p.h) & (xx >= 0) & (xx < p.w);
         xpix[m] = ok ? (img * p.h + yy) * p.w + xx : -1;
         xhalf[m] = (unsigned)(rem & 1) * 16u;
-        xlds[m] = (unsigned)((ky * C::KSUB * C::PX + px) * 32 + (rem & 1) * 16);   // + sub * PX * 32
+        const int plane = (rem & 1) * S + (S == 2 ? (px & 1) : 0), slot = S == 2 ? (px >> 1) : px;
+        xlds[m] = (unsigned)(((ky * C::KSUB * C::NPL + plane) * C::PSL + slot) * 16);   // + sub * NPL * PSL * 16
     });
     // per-thread pieces of the weight tile: offset inside one (tap, chunk) block of ct_total KiB, plus the tap's stride
     unsigned woff[C::NWP];
@@ -166,21 +194,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     const int kc_total = p.kc_total, ct_total = p.ct_total;
     uint4 xreg[C::NXP], wreg[C::NWP];
 
-    f32x16 acc[NT];
+    // wave w: output row yo + (w >> 1), pixels 64 (w & 1) .. + 63 of the strip as two MFMA pixel tiles; every weight
+    // fragment read from LDS feeds two MFMAs
+    f32x16 acc[2][NT];
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
+    for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pt][ct][r] = 0.0f;
 
-    const int pl = wave * 32 + (lane & 31);   // this lane's output pixel inside the strip
-    const int hl = lane >> 5;                 // which 8 of the chunk's 16 channels this lane feeds
+    const int wrow = wave >> 1;
+    const int pl = (wave & 1) * 64 + (lane & 31);   // this lane's first output pixel inside the strip (the second: + 32)
+    const int hl = lane >> 5;                       // which 8 of the chunk's 16 channels this lane feeds
 
     // Iteration st (a stage = KSUB chunks): [commit stage st to LDS] -> issue the global loads of stage st + 1 -> MFMAs
     // of stage st.  Iteration -1 only issues the loads of stage 0.  (Load and commit code exist once, inline: as lambdas
     // called from two places the compiler indexed their closure dynamically and every register array behind it moved to
     // scratch.)
     const int nstage = (kc_total + C::KSUB - 1) / C::KSUB;
-    const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)((pl * S * 2 + hl) * 16);
+    const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem +
+                           (unsigned)((((wrow * S * C::KSUB * 2 + hl) * S) * C::PSL + pl) * 16);
     const unsigned aaddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(C::X_BYTES + lane * 16);
     for (int st = -1; st < nstage; ++st) {
         if (st >= 0) {
@@ -189,7 +223,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                 constexpr int m = decltype(m_c)::value;
                 constexpr int sub = m / C::NXP1, m1 = m % C::NXP1;
                 const int q = tid + m1 * NTHREADS;
-                if (C::XP1 % NTHREADS == 0 || q < C::XP1) *(uint4*)(xt + xlds[m1] + sub * C::PX * 32) = xreg[m];
+                if (C::XP1 % NTHREADS == 0 || q < C::XP1) *(uint4*)(xt + xlds[m1] + sub * C::NPL * C::PSL * 16) = xreg[m];
             });
             g_for<0, C::NWP>([&](auto m_c) {
                 constexpr int m = decltype(m_c)::value;
@@ -214,12 +248,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                 }
                 const bool live = kc < kc_total;   // a stage may reach past the last chunk: zeros
                 const unsigned cbytes = (unsigned)cstride * 2u, soff = (unsigned)coff * 2u;
+#if defined(GEMM_EXP) && (GEMM_EXP & 2)
+                if (st < 0)
+#endif
                 g_for<0, C::NXP1>([&](auto m_c) {
                     constexpr int m = decltype(m_c)::value;
                     xreg[sub * C::NXP1 + m] = gemm_load16(xs, (live && xpix[m] >= 0) ? (unsigned)xpix[m] * cbytes + xhalf[m] : kOobOff, soff);
                 });
             });
             const unsigned wsoff = (unsigned)(ns * C::KSUB * ct_total) * 1024u;
+#if defined(GEMM_EXP) && (GEMM_EXP & 1)
+            if (st < 0)
+#endif
             g_for<0, C::NWP>([&](auto m_c) {
                 constexpr int m = decltype(m_c)::value;
                 const bool live = C::KSUB == 1 || ns * C::KSUB + wsub[m] < kc_total;
@@ -228,15 +268,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
         }
         __builtin_amdgcn_sched_barrier(0);   // the loads above stay in front of the MFMA section
         if (st < 0) continue;
-        // NSTEP steps of (1 pixel fragment + NT weight fragments -> NT MFMAs); the fragments of step i + 1 are requested
-        // before the MFMAs of step i, with counted waits
-        bf16x8 af[2][NT], bq[2];
+        // NSTEP steps of (2 pixel fragments + NT weight fragments -> 2 NT MFMAs); the fragments of step i + 1 are
+        // requested before the MFMAs of step i, with counted waits
+        bf16x8 af[2][NT], bq[2][2];
         g_for<0, C::NSTEP>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
             auto issue = [&](auto j_c) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_c)::value;
                 constexpr int sub = j / C::T, tap = j % C::T, ky = tap / KS, kx = tap % KS;
-                bq[j & 1] = g_lds_read<((ky * C::KSUB + sub) * C::PX + kx) * 32>(baddr);
+                constexpr int boff = (((ky * C::KSUB + sub) * C::NPL + (S == 2 ? (kx & 1) : 0)) * C::PSL + (S == 2 ? (kx >> 1) : kx)) * 16;
+                bq[j & 1][0] = g_lds_read<boff>(baddr);
+                bq[j & 1][1] = g_lds_read<boff + 32 * 16>(baddr);
                 g_for<0, NT>([&](auto ct_c) {
                     constexpr int ct = decltype(ct_c)::value;
                     af[j & 1][ct] = g_lds_read<(j * NT + ct) * 1024>(aaddr);
@@ -245,43 +287,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
             if constexpr (i == 0) issue(GInt<0>{});
             if constexpr (i + 1 < C::NSTEP) {
                 issue(GInt<i + 1>{});
-                g_lds_wait<NT + 1>();
+                g_lds_wait<NT + 2>();
             } else {
                 g_lds_wait<0>();   // nothing stays in flight across the barrier
             }
-            SRHIP_LOAD_FENCE(bq[i & 1]);
+            SRHIP_LOAD_FENCE(bq[i & 1][0]);
+            SRHIP_LOAD_FENCE(bq[i & 1][1]);
             g_for<0, NT>([&](auto ct_c) {
                 constexpr int ct = decltype(ct_c)::value;
                 SRHIP_LOAD_FENCE(af[i & 1][ct]);
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1], acc[ct], 0, 0, 0);
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][0], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][1], acc[1][ct], 0, 0, 0);
             });
         });
     }
 
     // epilogue: accumulator register r of lane l is output channel 32 ct + 8 (r >> 2) + 4 (l >> 5) + (r & 3) of pixel l & 31
-    const int xo = xo0 + pl;
-    if (xo >= p.wo) return;
-    const long long opix = ((long long)img * p.ho + yo) * p.wo + xo;
-    char* dp = p.dst + opix * p.cout_stride * 2;
-    const char* rp = p.res ? p.res + opix * p.cout_stride * 2 : nullptr;
+    const int yrow = yo + wrow;
+    if (yrow >= p.ho) return;
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
+    for (int pt = 0; pt < 2; ++pt) {
+        const int xo = xo0 + pl + 32 * pt;
+        if (xo >= p.wo) continue;
+        const long long opix = ((long long)img * p.ho + yrow) * p.wo + xo;
+        char* dp = p.dst + opix * p.cout_stride * 2;
+        const char* rp = p.res ? p.res + opix * p.cout_stride * 2 : nullptr;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = (ct0 + ct) * 32 + 8 * g + 4 * hl;
-            if (c0 >= p.cout_w) continue;
-            float v[4];
+        for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
-                const float t = acc[ct][4 * g + e] + bia;
-                v[e] = fmaxf(t, t * p.slope) * p.alpha;   // act(t) = max(t, slope * t), slope in {1, 0, s}
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = (ct0 + ct) * 32 + 8 * g + 4 * hl;
+                if (c0 >= p.cout_w) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
+                    const float t = acc[pt][ct][4 * g + e] + bia;
+                    v[e] = fmaxf(t, t * p.slope) * p.alpha;   // act(t) = max(t, slope * t), slope in {1, 0, s}
+                }
+                if (rp != nullptr) {
+                    const uint2 r = *(const uint2*)(rp + c0 * 2);
+                    v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                }
+                *(uint2*)(dp + c0 * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
-            if (rp != nullptr) {
-                const uint2 r = *(const uint2*)(rp + c0 * 2);
-                v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
-            }
-            *(uint2*)(dp + c0 * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
     }
 }
@@ -307,7 +356,7 @@ __global__ void gemm_pack_weights_kernel(const float* __restrict__ w, unsigned s
 }
 
 template <int KS, int S, int NT>
-int launch_gemm_nt(const GemmParams& p, int groups, hipStream_t stream)
+int launch_gemm_nt(GemmParams p, int groups, hipStream_t stream)
 {
     using C = GCfg<KS, S, NT>;
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];
@@ -320,9 +369,11 @@ int launch_gemm_nt(const GemmParams& p, int groups, hipStream_t stream)
         }
         configured_dev[dev].store(true, std::memory_order_release);
     }
-    const long long blocks = (long long)srhip_div_up(p.wo, TPX) * p.ho * p.n;
-    SRHIP_REQUIRE(blocks < (1ll << 31), "conv_gemm: too many work-groups");
-    hipLaunchKernelGGL((conv_gemm_kernel<KS, S, NT>), dim3((unsigned)blocks, (unsigned)groups), dim3(NTHREADS), C::LDS_BYTES, stream, p);
+    const long long units = (long long)srhip_div_up(p.wo, TPX) * srhip_div_up(p.ho, ROWS) * p.n * groups;
+    SRHIP_REQUIRE(units < (1ll << 30), "conv_gemm: too many work-groups");
+    p.units = (unsigned)units;
+    p.groups = groups;
+    hipLaunchKernelGGL((conv_gemm_kernel<KS, S, NT>), dim3((unsigned)((units + 7) / 8 * 8)), dim3(NTHREADS), C::LDS_BYTES, stream, p);
     return srhip_check_launch("conv_gemm_kernel");
 }
 
@@ -331,16 +382,13 @@ int launch_gemm_nt(const GemmParams& p, int groups, hipStream_t stream)
 template <int KS, int S>
 int launch_gemm(const GemmParams& p, hipStream_t stream)
 {
-    const int maxnt = S == 2 ? 4 : MAXNT;   // the stride-2 window needs more staging registers: 4 tiles fit without spills
+    const int maxnt = MAXNT;
     const int groups = srhip_div_up(p.ct_total, maxnt);
     const int nt = srhip_div_up(p.ct_total, groups);
     switch (nt) {
     case 1: return launch_gemm_nt<KS, S, 1>(p, groups, stream);
     case 2: return launch_gemm_nt<KS, S, 2>(p, groups, stream);
-    case 3: return launch_gemm_nt<KS, S, 3>(p, groups, stream);
-    case 4: return launch_gemm_nt<KS, S, 4>(p, groups, stream);
-    case 5: return launch_gemm_nt<KS, S, 5>(p, groups, stream);
-    default: return launch_gemm_nt<KS, S, 6>(p, groups, stream);
+    default: return launch_gemm_nt<KS, S, 3>(p, groups, stream);
     }
 }
 

@@ -388,7 +388,10 @@ def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: i
     as1x1 = (kh, kw, padding, stride) == (1, 1, 0, 1)
     gemm_ok = use_conv_gemm and kh == kw and kh in (1, 3) and stride in (1, 2) and padding in (0, 1) and padding <= kh // 2 \
         and alpha > 0.0 and len(srcs) <= 3 and all(t.shape[-1] % 16 == 0 for t in srcs)
-    if gemm_ok and not (as3x3 and stride == 1 and len(srcs) == 1 and cpad <= 64 and cout <= 64):
+    # a layer that is ONE launch of the register-resident kernel stays there (3x3 stride 1, or 1x1 as its centre tap: on
+    # the small ESA layers of RepRFN the implicit-GEMM kernel's staging costs more than the eight idle taps)
+    one_native = (as3x3 or as1x1) and stride == 1 and len(srcs) == 1 and cpad <= 64 and cout <= 64 and (alpha == 1.0 or as3x3)
+    if gemm_ok and not one_native:
         wp = _cached_pack(weight, ("gemm", cpad), lambda: conv_gemm_pack_weights(weight.detach().float().contiguous(), cpad))
         return conv_gemm(tuple(srcs), wp, None if bias is None else bias.detach(), cout, kh, stride=stride, padding=padding,
                          act=act, slope=slope, alpha=alpha, res=res)
