@@ -40,6 +40,10 @@ def test_gradient_map_golden(F_, z):
         assert np.abs(F_.gradient_map(dev(x)).cpu().numpy() - orc.gradient_map(x)).max() <= 2e-6
 
 
+def _bf16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
+
+
 @pytest.mark.parametrize("name", ["t64_64", "t192_192"])
 def test_conv_transpose_golden(F_, z, name):
     x, w, b = z[f"convT.{name}.x"], z[f"convT.{name}.w"], z[f"convT.{name}.b"]
@@ -59,6 +63,11 @@ def test_temporal_conv_shapes_golden(F_, z, name):
     got = F_.nhwc_bf16_to_nchw_f32(y, w.shape[0]).cpu().numpy()
     assert got.shape == z[key + ".y"].shape
     assert np.abs(got - z[key + ".y"]).max() <= 2e-2
+    # the fp32-accumulate bar: every one of these layers is ONE launch that accumulates its whole reduction in fp32, so
+    # against the oracle on the SAME bf16-rounded operands only the final bf16 rounding of the result remains
+    xr, wr = _bf16(x), _bf16(w)
+    ref = orc.conv2d(xr, wr, b, st, pd, act=1)
+    assert (np.abs(got - ref) <= 1e-3 + 2.0 ** -8 * np.abs(ref)).all()
 
 
 def test_conv2d_auto_wide_output_uses_mfma_slices(F_):
@@ -129,6 +138,8 @@ def test_conv_transpose_on_mfma_golden(F_, z, name):
         assert got.shape == z[f"convT.{name}.y"].shape
         assert np.abs(got - z[f"convT.{name}.y"]).max() <= 2e-2
         assert np.abs(got - orc.conv_transpose2x2s2(x, w, b, relu=True)).max() <= 2e-2
+        ref = orc.conv_transpose2x2s2(_bf16(x), _bf16(w), b, relu=True)      # fp32-accumulate bar on bf16-rounded operands
+        assert (np.abs(got - ref) <= 1e-3 + 2.0 ** -8 * np.abs(ref)).all()
 
 
 def test_depth_to_space_is_a_permutation(F_):
