@@ -255,6 +255,11 @@ SRHIP_API int srhip_upsample_grid_bilinear_bwd_nhwc(const void* ddst, const void
  *                                        un-added branch must be kept for the backward)
  * dst may alias an input. */
 SRHIP_API int srhip_relu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, void* stream);
+/* Sign bits (value > 0) of an (n, h, w, 64) bf16 map in the layout of srhip_conv3x3_args.aux, for a ReLU output whose
+ * producing launch cannot emit them itself (the two-source layer torch.concat + conv, core/models/model.py:169):
+ * the backward then applies the ReLU mask inside the data-gradient launch (SRHIP_AUX_MASKBITS) instead of a pass that
+ * reads two maps and writes one.  bits: srhip_conv3x3_signbits_bytes(n, h, w) bytes. */
+SRHIP_API int srhip_signbits_from_map_bf16(const void* map, void* bits, int n, int h, int w, void* stream);
 SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t count, void* stream);
 
 /* ESA attention helpers of RepRFN (core/arch/RepRFN.py:295-308) on NHWC bf16, c % 8 == 0:

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "srhip_upsample_grid_bilinear_bwd_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_upsample_grid_bilinear_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_relu_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "srhip_signbits_from_map_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "srhip_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "srhip_max_pool2d_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_resize_bilinear_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

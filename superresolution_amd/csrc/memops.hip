@@ -400,6 +400,38 @@ __device__ __forceinline__ unsigned add2(unsigned a, unsigned b)
 {
     return pack_bf16x2(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));
 }
+// Sign bits of a 64-channel bf16 map in the layout the convolution's sign-bit forms read (srhip_conv3x3_args.aux): word
+// (x / 32) * 64 + (x % 8) * 8 + c / 8 of a row, bit ((x % 32) / 8) * 8 + c % 8.  One thread = one word: four 16-byte
+// loads (pixels x0 + 8k, 8 channels), 8 lanes per pixel, so a wave reads 1 KiB of contiguous pixels per load.
+__global__ void signbits_from_map_kernel(const unsigned short* __restrict__ map, unsigned* __restrict__ bits, int w, int groups,
+                                         long long rows)
+{
+    // grid: (row groups of 4 words-rows per block ...): thread index -> (row, 32-pixel group, lane)
+    const long long total = rows * groups * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long long rg = i >> 6;
+        const long long row = rg / groups;
+        const int g = (int)(rg - row * groups);
+        const int xb = g * 32 + (lane >> 3);
+        const unsigned short* rp = map + (row * w) * 64 + (lane & 7) * 8;
+        unsigned word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = xb + 8 * k;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (x < w) v = *(const uint4*)(rp + (long long)x * 64);
+            const unsigned q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const short h = (short)((e & 1) ? (q[e >> 1] >> 16) : (q[e >> 1] & 0xffffu));   // bf16 > 0 <=> its bits as int16 > 0
+                word |= (h > 0 ? 1u : 0u) << (8 * k + e);
+            }
+        }
+        bits[i] = word;
+    }
+}
+
 __global__ void add_bf16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ dst,
                                 long long nvec)
 {
@@ -1713,6 +1745,18 @@ SRHIP_API int srhip_relu_mask_bf16(const void* dy, const void* y, void* dst, siz
     hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4*)dy, (const uint4*)y, (uint4*)dst, nvec);
     return srhip_check_launch("relu_mask_bf16");
+}
+
+SRHIP_API int srhip_signbits_from_map_bf16(const void* map, void* bits, int n, int h, int w, void* stream)
+{
+    SRHIP_REQUIRE(map && bits, "signbits_from_map_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1, "signbits_from_map_bf16: empty tensor");
+    SRHIP_REQUIRE((size_t)map % 16 == 0 && (size_t)bits % 4 == 0, "signbits_from_map_bf16: misaligned pointer");
+    const int groups = (w + 31) / 32;
+    const long long rows = (long long)n * h;
+    hipLaunchKernelGGL(signbits_from_map_kernel, dim3(grid_for(rows * groups * 64, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)map, (unsigned*)bits, w, groups, rows);
+    return srhip_check_launch("signbits_from_map_bf16");
 }
 
 SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t count, void* stream)

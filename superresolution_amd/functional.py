@@ -172,6 +172,17 @@ def signbits_empty(n: int, h: int, w: int, device) -> torch.Tensor:
     return t
 
 
+def signbits_from_map(y: torch.Tensor) -> torch.Tensor:
+    """Sign bits (y > 0) of an (n, h, w, 64) bf16 map, in the layout the convolution's sign-bit forms consume."""
+    y = _req(y, torch.bfloat16, "y")
+    n, h, w, c = y.shape
+    if c != 64:
+        raise ValueError("signbits_from_map: 64-channel maps only")
+    bits = signbits_empty(n, h, w, y.device)
+    check(lib.srhip_signbits_from_map_bf16(y.data_ptr(), bits.data_ptr(), n, h, w, _stream()))
+    return bits
+
+
 def signbits_unpack(bits: torch.Tensor, w: int) -> torch.Tensor:
     """(n, h, ceil(w/32), 64) int32 sign bits -> (n, h, w, 64) bool (torch ops; for tests and debugging).
     Pixel x, channel c: word (x//32)*64 + (x%8)*8 + c//8, bit ((x%32)//8)*8 + c%8."""

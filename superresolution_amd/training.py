@@ -86,6 +86,9 @@ class _SuperSamplerFn(torch.autograd.Function):
         g = prev
         # main trunk (model.py:82-95,169)
         xs = [m._conv("main_in", m.main.conv_in[0], up, fr, xb=g, cin_b=bf)]
+        # the two-source launch cannot emit its ReLU pattern itself: one light pass (reads the map, writes 1/16 of it)
+        # lets the backward mask inside the last data-gradient launch of the trunk
+        x0bits = F_.signbits_from_map(xs[0]) if (bits and sr == 64) else None
         ts = []
         for i, blk in enumerate(m.main.conv_main):
             # one launch per block; the intermediate map is written out as well (the backward needs it)
@@ -95,7 +98,7 @@ class _SuperSamplerFn(torch.autograd.Function):
         a = m._conv("after", m.after_main[0], up, fr, xb=xs[-1], cin_b=sr)
         c0 = m._conv("fin0", m.final_conv[0], a, sr)
         out = m._conv("fin2", m.final_conv[2], c0, sr, act=F_.ACT_NONE, out_nchw_f32=True)
-        sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]), bits=bits)
+        sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]), bits=bits, x0bits=x0bits)
         ctx.model, ctx.sv = m, sv
         return out
 
@@ -130,10 +133,13 @@ class _SuperSamplerFn(torch.autograd.Function):
             _wgrad(ts[i], dx, blk[2], grads, sr, scale=0.2, red=red)
             g2 = dgrad(f"m{i}b", blk[2], dx, alpha=0.2, mask=ts[i])
             _wgrad(xs[i], g2, blk[0], grads, sr, red=red)
-            dx = dgrad(f"m{i}a", blk[0], g2, res=dx)
+            if i == 0 and sv["x0bits"] is not None:   # ... and the ReLU of conv_in applied to the fan-in sum, same launch
+                dx = dgrad(f"m{i}a", blk[0], g2, res=dx, signbits=sv["x0bits"], aux_mode=F_.AUX_MASKBITS)
+            else:
+                dx = dgrad(f"m{i}a", blk[0], g2, res=dx)
         # conv_in on concat(up, g) (model.py:85,169)
         cin_ = m.main.conv_in[0]
-        d = F_.relu_mask(dx, xs[0], out=dx)
+        d = dx if sv["x0bits"] is not None else F_.relu_mask(dx, xs[0], out=dx)
         _wgrad(up, d, cin_, grads, fr, ci_off=0, red=red, last=False)
         _wgrad(g, d, cin_, grads, bf, ci_off=fr, with_bias=False, red=red)
         dup = dgrad("main_in", cin_, d, lo=0, n=fr, res=dup)

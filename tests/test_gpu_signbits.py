@@ -124,3 +124,15 @@ def test_full_size_signbit_roundtrip(F_):
     assert torch.equal(F_.signbits_unpack(bits[-1:], w), y[-1:] > 0)
     d, dm = F_.conv3x3(x, wp, None, 64, signbits=bits, aux_mode=F_.AUX_DUALBITS)
     assert torch.equal(dm, F_.relu_mask(d, y))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_signbits_from_map_equals_the_emitted_bits(F_, shape):
+    n, h, w = shape
+    x, wt, b, _ = _case(19 * h + w, n, h, w)
+    wp = F_.conv3x3_pack_weights(wt, 64, 64)
+    y, bits = F_.conv3x3(x, wp, b, 64, act=F_.ACT_RELU, aux_mode=F_.AUX_EMIT)
+    assert torch.equal(F_.signbits_unpack(F_.signbits_from_map(y), w), F_.signbits_unpack(bits, w))   # (bits of pixels >= w are unspecified)
+    z = (torch.randn(n, h, w, 64, generator=torch.Generator().manual_seed(w)) * 0.5).to(torch.bfloat16).cuda()   # signed map
+    z[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-38, -1e-38], dtype=torch.bfloat16)
+    assert torch.equal(F_.signbits_unpack(F_.signbits_from_map(z), w), z > 0)
