@@ -148,6 +148,9 @@ typedef struct {
     int act2;             /* srhip_act of the second layer */
     float slope2;         /* its LeakyReLU slope */
     float alpha;          /* > 0 */
+    int cout2;            /* 0 or 64: the form above.  1..32: HEAD form for the network's last two layers
+                             (core/models/model.py:111-115): wpack2 / bias2 hold a 64 -> cout2 layer, there is no residual,
+                             dst = alpha * act2(conv2(relu(conv1(src) + bias1)) + bias2) as fp32 NCHW (n, cout2, h, w) */
 } srhip_conv3x3_pair_args;
 SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* args, void* stream);
 

@@ -53,7 +53,7 @@ class Conv3x3PairArgs(ctypes.Structure):
         ("src", c_void_p), ("wpack1", c_void_p), ("bias1", c_void_p), ("wpack2", c_void_p), ("bias2", c_void_p),
         ("mid", c_void_p), ("dst", c_void_p),
         ("n", c_int), ("h", c_int), ("w", c_int),
-        ("act2", c_int), ("slope2", c_float), ("alpha", c_float),
+        ("act2", c_int), ("slope2", c_float), ("alpha", c_float), ("cout2", c_int),
     ]
 
 

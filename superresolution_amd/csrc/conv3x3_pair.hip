@@ -39,6 +39,7 @@ struct PairParams {
     int n, h, w;
     float slope2, alpha;
     int nstrips, nsegs, seg_h, total_items;
+    int cout2;   // head form: output channels (1..32) of the second layer, written as fp32 NCHW planes
 };
 
 struct PairCfg {
@@ -583,7 +584,126 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
     }
 }
 
-template <bool STORE_MID, int ACT2>
+// Head form of the second layer: 64 -> cout2 <= 32 channels (one MFMA tile), no residual, output fp32 NCHW -- the last two
+// layers of the network (core/models/model.py:111-115: Conv + ReLU -> Conv(64 -> 3)) as one launch.  Half the MFMAs of a
+// 64-channel second layer, so these waves wait for the first layer's most of the time: the launch costs what the first
+// layer alone costs, and the 64-channel map between the two layers never reaches memory.  Same barrier sequence, mid-ring
+// addressing and fragment pipeline as pair_second_layer; the epilogue goes straight from the accumulator to 4-byte plane
+// stores (lane = pixel: 128 contiguous bytes per half-wave and channel).
+template <int ACT2>
+__device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
+                                                const int lane)
+{
+    using P = PairCfg;
+    const int hl = lane >> 5, pl = lane & 31;
+    bf16x8 wreg[9][P::KC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kc = 0; kc < P::KC; ++kc) wreg[t][kc] = p.wpack2[(t * P::KC + kc) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<0, 9 * P::KC>([&](auto f_c) {   // the loads land before the row loop: see the first layer
+        SRHIP_CAPTURE(wreg);
+        constexpr int f = decltype(f_c)::value;
+        asm volatile("" : "+a"(wreg[f / P::KC][f % P::KC]));
+    });
+    // accumulator register r of this lane is output channel 8 (r >> 2) + 4 hl + (r & 3) of pixel pl
+    float breg[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 8 * (r >> 2) + 4 * hl + (r & 3);
+        breg[r] = (p.bias2 != nullptr && co < p.cout2) ? p.bias2[co] : 0.0f;
+    }
+    const int ngroups = (p.cout2 + 7) >> 3;   // register quads that hold real channels
+    unsigned rd[3][P::KC];  // as in the first layer
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = 32 * pg + pl + kx;
+#pragma unroll
+        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+    }
+    const int H = p.h, W = p.w;
+    bf16x8 bq[2][P::KC];
+    f32x16 acc;
+
+    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+        const PairItem it = pair_decode_item(p, item);
+        const int x0 = it.x0, y0 = it.y0, nout = it.nout;
+        const unsigned plane = (unsigned)(H * W) * 4u;
+        const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.dst + (long long)it.n * p.cout2 * plane), 0, (int)((unsigned)p.cout2 * plane), 0x00020000);
+        const int jq = 32 * pg + pl, xq = x0 + jq;   // output column within the strip / the image
+        const bool col_ok = jq < P::TWO && xq < W;
+
+        auto row_body = [&](auto par_c, const int o) {
+            constexpr int PAR = decltype(par_c)::value;
+            const int y = y0 + o;
+            unsigned rowa[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                rowa[ky] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(((o + ky) & (P::NY - 1)) * P::SLOT_BYTES);
+            if constexpr (PAR == 0) {
+                if (o == 0) {
+                    static_for<0, P::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[0][kc] = lds_read_b128(rowa[0] + rd[0][kc]);
+                    });
+                    lds_wait<0>();
+                    static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
+                }
+            }
+            static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg);
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                lds_wait<0>();
+                static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+                static_for<0, P::KC>([&](auto kc_c) {
+                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg);
+                    constexpr int kc = decltype(kc_c)::value;
+                    mfma_pinned<true, (t == 0 && kc == 0), 0>(acc, wreg[t][kc], bq[cur][kc]);
+                    bq[nxt][kc] = lds_read_b128(rowa[kyn] + rd[tn % 3][kc]);   // fragment kc of the next tap
+                });
+            });
+            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc));   // MFMA result -> the reads below
+            const unsigned soff = (unsigned)(y * W) * 4u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < ngroups) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = 8 * g + 4 * hl + e;
+                        const float t = acc[4 * g + e] + breg[4 * g + e];
+                        float v = t;
+                        if constexpr (ACT2 == 1) v = fmaxf(t, 0.0f);
+                        else if constexpr (ACT2 == 2) v = fmaxf(t, t * p.slope2);
+                        const unsigned vo = (col_ok && co < p.cout2) ? (unsigned)co * plane + (unsigned)xq * 4u : kOobOffset;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v * p.alpha), dst_rsrc, vo, soff, 0);
+                    }
+                }
+            }
+            lds_wait<0>();  // tap 8's fetch of the next row's tap 0: nothing stays in flight across rows
+            static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
+        };
+
+        __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
+        const int nsteps = nout + P::LAG;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += 2) {
+            __builtin_amdgcn_s_barrier();
+            if (s >= P::LAG) row_body(IntC<0>{}, s - P::LAG);
+            if (s + 1 < nsteps) {
+                __builtin_amdgcn_s_barrier();
+                if (s + 1 >= P::LAG) row_body(IntC<1>{}, s + 1 - P::LAG);
+            }
+        }
+    }
+}
+
+template <bool STORE_MID, int ACT2, bool HEAD = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -592,17 +712,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     if (wave < 2) pair_first_layer<STORE_MID>(p, smem, lds_base, wave, lane);
+    else if constexpr (HEAD) pair_head_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
     else pair_second_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
 }
 
-template <bool STORE_MID, int ACT2>
+template <bool STORE_MID, int ACT2, bool HEAD = false>
 int launch_pair(PairParams p, hipStream_t stream)
 {
     using P = PairCfg;
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];  // per device
     const int dev = srhip_current_device();
     if (!configured_dev[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 P::LDS_BYTES) != hipSuccess) {
             srhip_set_error("conv3x3_pair: cannot raise the dynamic LDS limit to %d", P::LDS_BYTES);
             return SRHIP_ERR_LAUNCH;
@@ -633,7 +754,7 @@ int launch_pair(PairParams p, hipStream_t stream)
     SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_pair: too many work items");
     p.total_items = (int)total;
     const int grid = (int)(total < slots ? total : slots);
-    hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
     return srhip_check_launch("conv3x3_pair_kernel");
 }
 
@@ -662,7 +783,15 @@ SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* a, void* str
     p.n = a->n; p.h = a->h; p.w = a->w;
     p.slope2 = a->act2 == SRHIP_ACT_NONE ? 1.0f : (a->act2 == SRHIP_ACT_RELU ? 0.0f : a->slope2);
     p.alpha = a->alpha;
+    p.cout2 = a->cout2;
     hipStream_t s = (hipStream_t)stream;
+    if (a->cout2 != 0 && a->cout2 != 64) {
+        SRHIP_REQUIRE(a->cout2 >= 1 && a->cout2 <= 32, "conv3x3_pair: cout2 must be 64 (or 0) or, for the head form, 1..32");
+        SRHIP_REQUIRE((long long)a->h * a->w * a->cout2 * 4 < (1ll << 31), "conv3x3_pair: head output too large for 32-bit offsets");
+        if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0, true>(p, s) : launch_pair<false, 0, true>(p, s);
+        if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1, true>(p, s) : launch_pair<false, 1, true>(p, s);
+        return a->mid != nullptr ? launch_pair<true, 2, true>(p, s) : launch_pair<false, 2, true>(p, s);
+    }
     if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0>(p, s) : launch_pair<false, 0>(p, s);
     if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1>(p, s) : launch_pair<false, 1>(p, s);
     return a->mid != nullptr ? launch_pair<true, 2>(p, s) : launch_pair<false, 2>(p, s);

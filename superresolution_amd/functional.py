@@ -218,15 +218,42 @@ def conv3x3_pair(x: torch.Tensor, wpack1: torch.Tensor, bias1: Optional[torch.Te
     return (out, mid) if keep_mid else out
 
 
+def conv3x3_pair_head(x: torch.Tensor, wpack1: torch.Tensor, bias1: Optional[torch.Tensor], wpack2: torch.Tensor,
+                      bias2: Optional[torch.Tensor], cout2: int, act2: int = ACT_NONE, slope2: float = 0.0, alpha: float = 1.0,
+                      keep_mid: bool = False):
+    """alpha * act2(conv2(relu(conv1(x) + b1)) + b2) with a 64 -> cout2 <= 32 second layer, as fp32 NCHW (N, cout2, H, W), in
+    ONE launch: the network's last two layers (core/models/model.py:111-115).  ``wpack2`` = conv3x3_pack_weights(w2, 64, 64)
+    of the (cout2, 64, 3, 3) weight.  ``keep_mid=True`` also returns relu(conv1(x) + b1) as an NHWC bf16 map."""
+    x = _req(x, torch.bfloat16, "x")
+    if x.dim() != 4 or x.shape[-1] != 64:
+        raise ValueError("conv3x3_pair_head: expected an (N,H,W,64) map")
+    if not 1 <= cout2 <= 32:
+        raise ValueError("conv3x3_pair_head: cout2 must be in 1..32")
+    n, h, w, _ = x.shape
+    if bias1 is not None:
+        bias1 = _req(bias1, torch.float32, "bias1")
+    if bias2 is not None:
+        bias2 = _req(bias2, torch.float32, "bias2")
+    out = torch.empty((n, cout2, h, w), dtype=torch.float32, device=x.device)
+    mid = torch.empty_like(x) if keep_mid else None
+    a = Conv3x3PairArgs(src=x.data_ptr(), wpack1=wpack1.data_ptr(), bias1=_ptr(bias1), wpack2=wpack2.data_ptr(), bias2=_ptr(bias2),
+                        mid=_ptr(mid), dst=out.data_ptr(), n=n, h=h, w=w, act2=act2, slope2=slope2, alpha=alpha, cout2=cout2)
+    check(lib.srhip_conv3x3_pair_fwd(a, _stream()))
+    return (out, mid) if keep_mid else out
+
+
 _wgrad_ws = {}
 
 
 def _wgrad_workspace(device) -> torch.Tensor:
-    ws = _wgrad_ws.get(device)
+    """Partial-tile workspace of the weight-gradient kernel, one per (device, stream): launches on one stream are ordered
+    and may share it; two streams running weight gradients at the same time must not (10.5 MB each)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _wgrad_ws.get(key)
     if ws is None:
         with torch.cuda.device(device):
             ws = torch.empty((lib.srhip_conv3x3_wgrad_workspace_bytes(),), dtype=torch.uint8, device=device)
-        _wgrad_ws[device] = ws
+        _wgrad_ws[key] = ws
     return ws
 
 

@@ -146,6 +146,19 @@ class SuperSampler(nn.Module):
         out = self._conv(name + "b", conv_b, t, ch, res=x, act=act2, alpha=alpha)
         return (out, t) if keep_mid else out
 
+    def _pair_head(self, name: str, conv_a: nn.Conv2d, conv_b: nn.Conv2d, x: Tensor, keep_mid: bool = False):
+        """conv_b(relu(conv_a(x))) as fp32 NCHW, the network's last two layers (model.py:111-115), as one launch when
+        conv_a is 64 -> 64 and conv_b has at most 32 outputs; the 64-channel map between them stays in LDS."""
+        ch = x.shape[-1]
+        if self.use_pair_kernel and os.environ.get("SRHIP_NO_PAIR_HEAD", "0") != "1" and ch == 64 and conv_a.out_channels == 64 \
+                and conv_b.out_channels <= 32:
+            wa, wb = self._pack(name + "0", conv_a, ch, ch), self._pack(name + "2", conv_b, ch, ch)
+            return F_.conv3x3_pair_head(x, wa, conv_a.bias.detach(), wb, conv_b.bias.detach(), conv_b.out_channels,
+                                        keep_mid=keep_mid)
+        t = self._conv(name + "0", conv_a, x, ch)
+        out = self._conv(name + "2", conv_b, t, ch, act=F_.ACT_NONE, out_nchw_f32=True)
+        return (out, t) if keep_mid else out
+
     # ------------------------------------------------------------------ forward
     def forward(self, batch: Dict[str, Union[Tensor, int]]):
         lr_frames = batch.pop("lr_frames")
@@ -187,5 +200,4 @@ class SuperSampler(nn.Module):
             x = self._pair(f"m{i}", blk.blks[0], blk.blks[2], x, F_.ACT_NONE, 0.2)
         # after_main on concat(up, x) (model.py:170), final_conv (model.py:111-115,172)
         x = self._conv("after", self.after_main[0], up, fr, xb=x, cin_b=self.SR_CH)
-        x = self._conv("fin0", self.final_conv[0], x, self.SR_CH)
-        return self._conv("fin2", self.final_conv[2], x, self.SR_CH, act=F_.ACT_NONE, out_nchw_f32=True)
+        return self._pair_head("fin", self.final_conv[0], self.final_conv[2], x)

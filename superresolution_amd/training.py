@@ -96,8 +96,7 @@ class _SuperSamplerFn(torch.autograd.Function):
             ts.append(t)
             xs.append(x_next)
         a = m._conv("after", m.after_main[0], up, fr, xb=xs[-1], cin_b=sr)
-        c0 = m._conv("fin0", m.final_conv[0], a, sr)
-        out = m._conv("fin2", m.final_conv[2], c0, sr, act=F_.ACT_NONE, out_nchw_f32=True)
+        out, c0 = m._pair_head("fin", m.final_conv[0], m.final_conv[2], a, keep_mid=True)   # one launch, c0 kept for the backward
         sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]), bits=bits, x0bits=x0bits)
         ctx.model, ctx.sv = m, sv
         return out

@@ -111,3 +111,42 @@ def test_pair_rejects_bad_arguments(F_):
         F_.conv3x3_pair(x, wp, None, wp, None, out=x)
     with pytest.raises(SrhipError):
         F_.conv3x3_pair(x, wp, None, wp, None, alpha=0.0)
+
+
+@pytest.mark.parametrize("shape", [(1, 20, 70), (2, 37, 130), (1, 5, 3), (1, 9, 125), (3, 1, 1)])
+@pytest.mark.parametrize("cout2", [3, 8, 32])
+def test_pair_head_matches_oracle_and_two_launches(F_, shape, cout2):
+    """Head form: conv 64 -> 64 + ReLU -> conv 64 -> cout2 as fp32 NCHW in one launch (core/models/model.py:111-115)."""
+    from oracle import oracle as orc
+    n, h, w = shape
+    x, w1, b1, w2, b2 = _case(300 * h + w + cout2, n, h, w)
+    w2, b2 = w2[:cout2].contiguous(), b2[:cout2].contiguous()
+    xc = x.cuda()
+    wp1 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64)
+    wp2 = F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    out, mid = F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), cout2, keep_mid=True)
+    out_nomid = F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), cout2)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (n, cout2, h, w) and out.dtype == torch.float32
+    assert torch.equal(out, out_nomid)
+    # the two launches it replaces, on the kernel's own intermediate map: same arithmetic up to the summation order
+    ref2 = F_.conv3x3(mid, wp2, b2.cuda(), cout2, act=F_.ACT_NONE, out_nchw_f32=True)
+    assert float((out - ref2).abs().max()) <= 1e-4
+    t = F_.conv3x3(xc, wp1, b1.cuda(), 64, act=F_.ACT_RELU)
+    assert float((mid.float() - t.float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(t.float().abs().max()))
+    # the oracle with the intermediate map rounded where the kernel rounds it: fp32 accumulate, fp32 output
+    xn = x.float().permute(0, 3, 1, 2).contiguous().numpy()
+    mid32 = np.maximum(orc.conv2d(xn, w1.numpy(), b1.numpy(), 1, 1), 0.0)
+    ref = orc.conv2d(_bf16_round(mid32), w2.numpy(), b2.numpy(), 1, 1)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-2      # a few intermediate elements land on the neighbouring bf16 value
+    ref_own = orc.conv2d(mid.float().permute(0, 3, 1, 2).cpu().numpy(), w2.numpy(), b2.numpy(), 1, 1)
+    assert np.abs(out.cpu().numpy() - ref_own).max() <= 1e-3  # the fp32-accumulate bar on the kernel's own intermediate map
+
+
+def test_pair_head_rejects_bad_arguments(F_):
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16, device="cuda")
+    wp = F_.conv3x3_pack_weights(torch.zeros(64, 64, 3, 3, device="cuda"), 64, 64)
+    with pytest.raises(ValueError):
+        F_.conv3x3_pair_head(x, wp, None, wp, None, 40)
+    with pytest.raises(ValueError):
+        F_.conv3x3_pair_head(x[..., :32].contiguous(), wp, None, wp, None, 3)
