@@ -237,7 +237,42 @@ def cpu_baseline(crop):
     res["oracle"] = {"value": (ch * cw) / float(LR_H * LR_W) / dto, "unit": "frames/s", "cores": cores, "kind": "port",
                      "sample": f"oracle/oracle.c forward on one LR {ch}x{cw} -> HR {ch * SCALE}x{cw * SCALE} crop ({dto:.2f} s), "
                                f"scaled by pixel count to a 540x960 -> 2160x3840 frame"}
+    res["ops"] = cpu_baseline_ops(cores)
     return res
+
+
+def cpu_baseline_ops(cores):
+    """The two memory-bound neighbours the GPU line carries as `warp_gbps` / `pixel_shuffle_gbps`, with the stock torch CPU
+    operators the reference calls (core/tools/math.py:10-17 -> F.grid_sample; core/arch/RepRFN.py:272 -> PixelShuffle) at
+    the same 4K shapes: algorithmic GB/s, median of 3."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    fr = torch.rand(1, 3, HR_H, HR_W, generator=g)
+    mv = (torch.randn(1, 2, HR_H, HR_W, generator=g) * 4).clamp(-32, 32)
+
+    def warp():
+        col = torch.arange(HR_W, dtype=torch.float32).view(1, 1, HR_W)
+        row = torch.arange(HR_H, dtype=torch.float32).view(1, HR_H, 1)
+        gx = ((col + mv[:, 0]) / (HR_W - 1)) * 2 - 1
+        gy = ((row + mv[:, 1]) / (HR_H - 1)) * 2 - 1
+        return F.grid_sample(fr, torch.stack((gx, gy), dim=-1), mode="bilinear", padding_mode="zeros", align_corners=True)
+
+    x = torch.rand(1, 48, LR_H, LR_W, generator=g)
+
+    def med(fn):
+        fn()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[1]
+
+    with torch.no_grad():
+        tw, tp = med(warp), med(lambda: F.pixel_shuffle(x, 4))
+    return {"warp_gbps": (2 * 3 + 2) * HR_H * HR_W * 4 / tw / 1e9, "pixel_shuffle_gbps": 2 * 48 * LR_H * LR_W * 4 / tp / 1e9,
+            "cores": cores, "sample": "F.grid_sample warp of a 3-channel fp32 2160x3840 frame by per-pixel vectors (grid built as "
+                                      "core/tools/math.py:12-15) and F.pixel_shuffle of (1,48,540,960) fp32, median of 3"}
 
 
 def cpu_baseline_train(crop):
