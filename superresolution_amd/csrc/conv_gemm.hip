@@ -27,7 +27,7 @@
 //     comes from the map that holds it.
 //   * Epilogue straight from the accumulators: lane (pixel, 4 consecutive channels) -> bias, activation, alpha,
 //     residual, bf16 pack, one 8-byte store.
-// -DGEMM_EXP=1|2|3 builds timing-only variants (no weight / input / any global loads after the first stage).
+// -DGEMM_EXP=<bits> builds timing-only variants: 1 no weight loads, 2 no input loads after the first stage, 4 no stores.
 #include <atomic>
 
 #include "srhip_common.h"
@@ -62,6 +62,7 @@ struct GemmParams {
     unsigned wbytes;   // size of the packed weights
     unsigned units;    // work-groups that have work
     int groups;        // output-channel groups of NT tiles
+    int vec16;         // dst pixel rows are 16-byte aligned: the epilogue goes through LDS to 16-byte pixel-major stores
 };
 
 template <int KS, int S, int NT>
@@ -84,7 +85,11 @@ struct GCfg {
     static constexpr int NPL = 2 * S;
     static constexpr int PSL = (PX + S - 1) / S;
     static constexpr int X_BYTES = KSUB * KR * NPL * PSL * 16;
-    static constexpr int LDS_BYTES = X_BYTES + NSTEP * NT * 1024;   // + [chunk][tap][tile][1 KiB]
+    static constexpr int STAGE_LDS = X_BYTES + NSTEP * NT * 1024;   // + [chunk][tap][tile][1 KiB]
+    // epilogue staging: per wave 64 pixels x (NT * 32 channels bf16 + 16 B padding), pixel-major
+    static constexpr int OUT_ROWB = NT * 64 + 16;
+    static constexpr int OUT_WAVE = 64 * OUT_ROWB;
+    static constexpr int LDS_BYTES = STAGE_LDS > 4 * OUT_WAVE ? STAGE_LDS : 4 * OUT_WAVE;
     static_assert(NSTEP * NT * 1024 < 65536, "weight fragments are addressed by the LDS instruction's 16-bit offset");
 };
 
@@ -304,6 +309,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
 
     // epilogue: accumulator register r of lane l is output channel 32 ct + 8 (r >> 2) + 4 (l >> 5) + (r & 3) of pixel l & 31
     const int yrow = yo + wrow;
+    if (p.vec16) {
+        // Straight from the accumulators a lane holds 4 channels of one pixel, and a store instruction would write 64
+        // separate 8-byte pieces (measured: the stores of a 160 -> 160 1x1 layer cost a third of its launch).  Instead the
+        // wave transposes its 64 x (NT * 32) results through LDS and writes 16 bytes per lane, consecutive lanes =
+        // consecutive channels of a pixel.
+        __syncthreads();   // every wave is done with the last stage's window and weights
+        char* ow = smem + wave * C::OUT_WAVE;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int px = 32 * pt + (lane & 31);
+            const int xo = xo0 + pl + 32 * pt;
+            const long long opix = ((long long)img * p.ho + yrow) * p.wo + xo;
+            const bool live = xo < p.wo && yrow < p.ho;
+            const char* rp = (p.res && live) ? p.res + opix * p.cout_stride * 2 : nullptr;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = ct * 32 + 8 * g + 4 * hl, c0 = ct0 * 32 + cl;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
+                        const float t = acc[pt][ct][4 * g + e] + bia;
+                        v[e] = fmaxf(t, t * p.slope) * p.alpha;   // act(t) = max(t, slope * t), slope in {1, 0, s}
+                    }
+                    if (rp != nullptr && c0 < p.cout_w) {
+                        const uint2 r = *(const uint2*)(rp + c0 * 2);
+                        v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                    }
+                    *(uint2*)(ow + px * C::OUT_ROWB + cl * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            }
+        }
+        // (the wave reads back only what it wrote itself: no barrier)
+        if (yrow >= p.ho) return;
+        constexpr int PPP = NT * 4;   // 16-byte pieces per pixel
+#pragma unroll
+        for (int j = 0; j < PPP; ++j) {
+            const int i = lane + 64 * j;
+            const int px = i / PPP, cg = i - px * PPP;
+            const int xo = xo0 + (wave & 1) * 64 + px;
+            const int c0 = ct0 * 32 + cg * 8;
+            if (xo < p.wo && c0 < p.cout_w) {
+                const long long opix = ((long long)img * p.ho + yrow) * p.wo + xo;
+#if defined(GEMM_EXP) && (GEMM_EXP & 4)
+                if (xo == -12345)
+#endif
+                *(uint4*)(p.dst + (opix * p.cout_stride + c0) * 2) = *(const uint4*)(ow + px * C::OUT_ROWB + cg * 16);
+            }
+        }
+        return;
+    }
     if (yrow >= p.ho) return;
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
@@ -455,6 +513,7 @@ SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* a, void* stream)
     SRHIP_REQUIRE(a->cout_stride >= p.cout_w && a->cout_stride % 4 == 0, "conv_gemm: cout_stride %d must hold pad16(cout) = %d channels", a->cout_stride, p.cout_w);
     SRHIP_REQUIRE((size_t)a->dst % 8 == 0 && (a->res == nullptr || (size_t)a->res % 8 == 0), "conv_gemm: dst / res must be 8-byte aligned");
     p.pad = a->pad;
+    p.vec16 = ((size_t)a->dst % 16 == 0 && a->cout_stride % 8 == 0) ? 1 : 0;
     p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
     p.alpha = a->alpha;
     {
