@@ -84,6 +84,16 @@ def suite(verbose=True):
     line("nearest down x4 f32 10ch from 4K", timeit(lambda: F_.nearest_down(g, 0.25)), 2 * 10 * h * w * 4)
     y = bf(1, H, W, 64)
     line("relu mask bf16 64ch @4K", timeit(lambda: F_.relu_mask(b, y)), 3 * 64 * H * W * 2)
+    # channels-first LayerNorm (core/arch/CAMixerSR.py:29-37) on a 64-channel fp32 NCHW map at LR, forward and backward
+    xl, wl, bl = f32(1, 64, h, w), f32(64), f32(64)
+    line("layernorm_cf fwd f32 64ch @LR", timeit(lambda: F_.layernorm_cf(xl, wl, bl)), 2 * 64 * h * w * 4)
+    dyl = f32(1, 64, h, w)
+    line("layernorm_cf bwd f32 64ch @LR", timeit(lambda: F_.layernorm_cf_bwd(xl, wl, dyl)), 3 * 64 * h * w * 4)
+    # backward of the fixed-ratio up-sampling (gather form, ReLU of the producer fused) and of the fp32 warp (scatter-add)
+    dup = bf(1, H, W, 32)
+    line("upsample x4 bwd bf16 NHWC 32ch 4K -> LR", timeit(lambda: F_.upsample_grid_bilinear_bwd_nhwc(dup, h, w, relu_out=fm)), 32 * (h * w * 2 + H * W) * 2)
+    frl, mvl, dyw = f32(1, 3, h, w), torch.randn(1, 2, h, w, device=dev), f32(1, 3, h, w)
+    line("warp bilinear bwd f32 NCHW 3ch @LR", timeit(lambda: F_.backward_warp_bwd(frl, mvl, dyw, True)), (3 * 3 + 2 + 2) * h * w * 4)
     sr, tg = f32(1, 3, H, W), f32(1, 3, H, W)
     line("fused L1+SSIM fwd+bwd 3ch @4K", timeit(lambda: F_.l1_ssim_loss(sr, tg, 1.0, 0.5, 0.0, 10.0)), 11 * 3 * H * W * 4)
 
