@@ -90,16 +90,54 @@ __device__ __forceinline__ unsigned relu_bf16x2(unsigned v)
     const s16x2 z = {0, 0};
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
 }
-__device__ __forceinline__ void lds_write_b64(unsigned addr, unsigned lo, unsigned hi)
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64_off(unsigned addr, unsigned lo, unsigned hi)
 {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
     const unsigned long long d = (unsigned long long)lo | ((unsigned long long)hi << 32);
-    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(d) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(d), "n"(OFF) : "memory");
+}
+// addr ^ (C << 4) as an instruction the optimiser cannot hoist: with compile-time ring slots the 8 swizzled write
+// addresses of a row are loop invariants, and 8 more live registers do not exist in the first-layer waves.
+template <int C, bool OPAQUE>
+__device__ __forceinline__ unsigned xor_slot16(unsigned addr)
+{
+    if constexpr (!OPAQUE) return addr ^ (unsigned)(C << 4);
+    unsigned r;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(C << 4), "v"(addr));
+    return r;
 }
 __device__ __forceinline__ u32x4 lds_read_u32x4(unsigned addr)
 {
     u32x4 r;
     asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
     return r;
+}
+// Fragment read whose ring slot enters through the instruction's 16-bit offset field: the row loops are unrolled over
+// the ring (8 x rows, 4 mid rows), so the slot of every read is a compile-time constant and no address arithmetic runs
+// per read (one vector add per fragment otherwise: 36 per row and wave).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_u32x4_off(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128_off(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// slot offset in the instruction (IMM) or added to the address
+template <bool IMM, int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128_sel(unsigned dyn_off, unsigned addr)
+{
+    if constexpr (IMM) return lds_read_b128_off<OFF>(addr);
+    else return lds_read_b128(dyn_off + addr);
 }
 
 struct PairItem {
@@ -128,6 +166,8 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
 {
     using P = PairCfg;
     const int hl = lane >> 5, pl = lane & 31;
+    constexpr bool IMM = !STORE_MID;               // compile-time ring slots (see `step`)
+    constexpr int UNR = IMM ? P::RING : 2;         // copies of the row loop's body
     // vector-memory schedule of one step: taps 0..3 [mid store of row s-2 (STORE_MID)] [DMA piece t of x row s+LA],
     // tap 4 [DMA piece 4]; the last DMA is the last operation of the step.
     constexpr int VM_STEP = P::MAXP + (STORE_MID ? 4 : 0);
@@ -168,15 +208,17 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
     for (int kx = 0; kx < 3; ++kx) {
         const int px = 32 * pg + pl + kx;
 #pragma unroll
-        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = lds_base + (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
     }
     const int q = 32 * pg + pl;                                             // this lane's mid pixel in the row image
-    const unsigned wy = (unsigned)(q * 128 + 8 * hl + (((q >> 1) & 7) << 4));  // its quad (ct, g) goes to wy ^ ((4 ct + g) << 4)
+    // its quad (ct, g) goes to wy ^ ((4 ct + g) << 4) of the row's slot (slot offsets are multiples of 1 KiB: the XOR
+    // of bits 4..6 commutes with adding them, so the slot enters through the write's offset field)
+    const unsigned wy = lds_base + (unsigned)P::YRING_OFF + (unsigned)(q * 128 + 8 * hl + (((q >> 1) & 7) << 4));
     unsigned rb[4];  // read-back for the mid store: group k = pixels 32 pg + 8 k + (lane >> 3), chunk lane & 7
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int qk = 32 * pg + 8 * k + (lane >> 3);
-        rb[k] = (unsigned)(qk * 128 + (((lane & 7) ^ ((qk >> 1) & 7)) << 4));
+        rb[k] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(qk * 128 + (((lane & 7) ^ ((qk >> 1) & 7)) << 4));
     }
 
     const int H = p.h, W = p.w;
@@ -243,8 +285,13 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             o1 = relu_bf16x2(pack_bf16x2(a[4 * g + 2], a[4 * g + 3])) & ymask;
         };
 
-        auto step = [&](auto par_c, const int s) {
-            constexpr int PAR = decltype(par_c)::value;
+        // IMM (the form that does not store mid): the row loop is unrolled over the x ring, Q = s mod RING, so the slots
+        // of rows s .. s+2 and of mid row s-1 are compile-time constants that enter through the offset field of the LDS
+        // instructions.  The form that stores mid has no registers left for eight copies of the loop body's live ranges:
+        // it is unrolled over the row parity only (Q = s mod 2) and adds the slot offsets per access.
+        auto step = [&](auto q_c, const int s) {
+            constexpr int Q = decltype(q_c)::value;
+            constexpr int PAR = Q & 1;
             const bool compute = s < nout + 2;
             if (compute) {
                 if (s == 0) vm_wait<0>();
@@ -256,9 +303,14 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             // mid row s-1 (accumulators of the other parity) goes to slot (s-1) & 3; rows outside the image are zeros
             const int yr = s - 1;
             const int yimg = y0 - 1 + yr;
-            const unsigned yslot = lds_base + (unsigned)P::YRING_OFF + (unsigned)((yr & (P::NY - 1)) * P::SLOT_BYTES);
+            // offset of slot (s - 1) mod NY: in the instruction (IMM) or added to the address registers
+            constexpr int YSLOT = IMM ? ((Q + P::NY - 1) & (P::NY - 1)) * P::SLOT_BYTES : 0;
+            const unsigned yslot_dyn = IMM ? 0u : (unsigned)((yr & (P::NY - 1)) * P::SLOT_BYTES);
+            const unsigned wys = wy + yslot_dyn;
+            unsigned rowx[3];   // !IMM: x-ring slot offsets of rows s .. s+2
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) rowx[ky] = IMM ? 0u : (unsigned)(((s + ky) & (P::RING - 1)) * P::SLOT_BYTES);
             const unsigned ymask = (s >= 1 && yimg >= 0 && yimg < H) ? colmask : 0u;
-            const unsigned wyr = yslot + wy;
             // mid row s-2 (read back at the end of step s-1) goes to HBM if it is one of the segment's own rows
             const int mr = s - 2;
             const unsigned mid_soff = (mr >= 1 && mr <= nout) ? (unsigned)(y0 - 1 + mr) * row_pitch : kOobOffset;
@@ -271,7 +323,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                         constexpr int t = decltype(t_c)::value;
                         unsigned o0, o1;
                         quad_pack(acc[PAR ^ 1][t / 4], IntC<t % 4>{}, ymask, o0, o1);
-                        lds_write_b64(wyr ^ (unsigned)((4 * (t / 4) + (t % 4)) << 4), o0, o1);
+                        lds_write_b64_off<YSLOT>(xor_slot16<4 * (t / 4) + (t % 4), IMM>(wys), o0, o1);
                     });
                     if constexpr (STORE_MID) {
                         static_for<0, 4>([&](auto k_c) {
@@ -286,15 +338,12 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
 
             const unsigned dma_soff = row_soff(s + P::LA);
             const unsigned dma_slot = (unsigned)(((s + P::LA) & (P::RING - 1)) * P::SLOT_BYTES);
-            unsigned rowa[3];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) rowa[ky] = lds_base + (unsigned)(((s + ky) & (P::RING - 1)) * P::SLOT_BYTES);
 
-            if constexpr (PAR == 0) {
+            if constexpr (Q == 0) {
                 if (s == 0) {  // first row of the item: nobody fetched its tap 0 yet
                     static_for<0, P::KC>([&](auto kc_c) {
                         constexpr int kc = decltype(kc_c)::value;
-                        bq[0][kc] = lds_read_b128(rowa[0] + rd[0][kc]);
+                        bq[0][kc] = lds_read_b128_sel<IMM, 0>(rowx[0], rd[0][kc]);
                     });
                     lds_wait<0>();
                     static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
@@ -323,7 +372,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                     // gaps 1..KC: pixel fragments of the next tap (tap 8: tap 0 of the next row, whose x rows are resident)
                     if constexpr (ml >= 1 && ml <= P::KC) {
                         constexpr int kr = ml - 1;
-                        bq[nxt][kr] = lds_read_b128(rowa[kyn] + rd[tn % 3][kr]);
+                        bq[nxt][kr] = lds_read_b128_sel<IMM, ((Q + kyn) & (P::RING - 1)) * P::SLOT_BYTES>(rowx[kyn], rd[tn % 3][kr]);
                     }
                     // taps 0..7: quad t of the previous row's accumulators -> mid ring
                     if constexpr (t < 8) {
@@ -332,14 +381,14 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                         if constexpr (ml == 1) e_p1 = pack_bf16x2(acc[PAR ^ 1][qct][4 * qg + 2], acc[PAR ^ 1][qct][4 * qg + 3]);
                         if constexpr (ml == 2) e_p0 = relu_bf16x2(e_p0) & ymask;
                         if constexpr (ml == 3) e_p1 = relu_bf16x2(e_p1) & ymask;
-                        if constexpr (ml == 5) e_addr = wyr ^ (unsigned)((4 * qct + qg) << 4);
-                        if constexpr (ml == 7) lds_write_b64(e_addr, e_p0, e_p1);
+                        if constexpr (ml == 5) e_addr = xor_slot16<4 * qct + qg, IMM>(wys);
+                        if constexpr (ml == 7) lds_write_b64_off<YSLOT>(e_addr, e_p0, e_p1);
                     }
                     if constexpr (STORE_MID && t < 4 && ml == 5)
                         buffer_store_b128_guarded(midv[t], mid_srd, mvo[t], mid_soff);
                     if constexpr (t < P::MAXP && ml == 6) issue_piece(IntC<t + 0 * ml>{}, dma_soff, dma_slot);
                     // tap 8: read the finished mid row (this wave's 32 pixels) back pixel-major for the store in the next step
-                    if constexpr (STORE_MID && t == 8 && ml >= 4) midv[ml - 4] = lds_read_u32x4(yslot + rb[ml - 4]);
+                    if constexpr (STORE_MID && t == 8 && ml >= 4) midv[ml - 4] = lds_read_u32x4_off<YSLOT>(yslot_dyn + rb[ml - 4]);
                     __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
                 });
             });
@@ -359,9 +408,16 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
         }
         const int nsteps = nout + P::LAG;
 #pragma unroll 1
-        for (int s = 0; s < nsteps; s += 2) {
-            step(IntC<0>{}, s);
-            if (s + 1 < nsteps) step(IntC<1>{}, s + 1);
+        for (int s = 0; s < nsteps; s += UNR) {
+            if constexpr (UNR == 2) {
+                step(IntC<0>{}, s);
+                if (s + 1 < nsteps) step(IntC<1>{}, s + 1);
+            } else {
+                static_for<0, UNR>([&](auto q_c) {
+                    constexpr int Q = decltype(q_c)::value;
+                    if (Q == 0 || s + Q < nsteps) step(q_c, s + Q);
+                });
+            }
         }
     }
 }
@@ -411,12 +467,13 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
     float breg[8];  // alpha * bias of this lane's 8 store-time channels
 #pragma unroll
     for (int r = 0; r < 8; ++r) breg[r] = (p.bias2 != nullptr ? p.bias2[st_c * 8 + r] : 0.0f) * p.alpha;
-    unsigned rd[3][P::KC];  // as in the first layer
+    unsigned rd[3][P::KC];  // as in the first layer, based at the mid ring
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int px = 32 * pg + pl + kx;
 #pragma unroll
-        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+        for (int kr = 0; kr < P::KC; ++kr)
+            rd[kx][kr] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
     }
     unsigned rres[NRES];  // residual of store group k: x-ring pixel 2 + 32 pg + 8 k + st_q (output column + 2), chunk st_c
 #pragma unroll
@@ -471,22 +528,20 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
             buffer_store_b128_guarded(o, dst_srd, vox[k], store_soff);
         };
 
-        // One output row.  PAR = o & 1 selects the fragment buffer that holds tap 0 and the residual set.
-        auto row_body = [&](auto par_c, const int o) {
-            constexpr int PAR = decltype(par_c)::value;
+        // One output row.  Q = o mod NY fixes the mid-ring slots of rows o .. o+2 (compile-time fragment addresses);
+        // PAR = o & 1 selects the fragment buffer that holds tap 0 and the residual set.
+        auto row_body = [&](auto q_c, const int o) {
+            constexpr int Q = decltype(q_c)::value;
+            constexpr int PAR = Q & 1;
             const int y = y0 + o;
             const unsigned xrow = lds_base + (unsigned)(((o + 2) & (P::RING - 1)) * P::SLOT_BYTES);  // x row of this output row
             const unsigned st_soff = o > 0 ? (unsigned)(y - 1) * row_pitch : kOobOffset;
-            unsigned rowa[3];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-                rowa[ky] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(((o + ky) & (P::NY - 1)) * P::SLOT_BYTES);
 
-            if constexpr (PAR == 0) {
+            if constexpr (Q == 0) {
                 if (o == 0) {
                     static_for<0, P::KC>([&](auto kc_c) {
                         constexpr int kc = decltype(kc_c)::value;
-                        bq[0][kc] = lds_read_b128(rowa[0] + rd[0][kc]);
+                        bq[0][kc] = lds_read_b128_off<0>(rd[0][kc]);
                     });
                     lds_wait<0>();
                     static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
@@ -523,7 +578,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                     if constexpr (ml == 0 && (t % 2 == 1) && (t / 2 < NRES)) resv[PAR][t / 2] = lds_read_u32x4(xrow + rres[t / 2]);
                     if constexpr (ml >= 1 && ml <= P::KC) {
                         constexpr int kr = ml - 1;
-                        bq[nxt][kr] = lds_read_b128(rowa[kyn] + rd[tn % 3][kr]);
+                        bq[nxt][kr] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kr]);
                     }
                     static_for<ml * NS / P::MPT, (ml + 1) * NS / P::MPT>([&](auto s_c) {
                         SRHIP_CAPTURE(resv); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
@@ -554,15 +609,17 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
 
         __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
         const int nsteps = nout + P::LAG;
+        static_assert(P::LAG % P::NY == 0, "the row's ring phase is the step's");
 #pragma unroll 1
-        for (int s = 0; s < nsteps; s += 2) {
-            // step s: output row s - LAG (LAG is even: the row parity is the step parity)
-            __builtin_amdgcn_s_barrier();
-            if (s >= P::LAG) row_body(IntC<0>{}, s - P::LAG);
-            if (s + 1 < nsteps) {
-                __builtin_amdgcn_s_barrier();
-                if (s + 1 >= P::LAG) row_body(IntC<1>{}, s + 1 - P::LAG);
-            }
+        for (int s = 0; s < nsteps; s += P::NY) {
+            // step s + Q: output row s + Q - LAG
+            static_for<0, P::NY>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+                if (Q == 0 || s + Q < nsteps) {
+                    __builtin_amdgcn_s_barrier();
+                    if (s + Q >= P::LAG) row_body(q_c, s + Q - P::LAG);
+                }
+            });
         }
         // drain: second epilogue half of the last row
         {
@@ -616,12 +673,13 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
         breg[r] = (p.bias2 != nullptr && co < p.cout2) ? p.bias2[co] : 0.0f;
     }
     const int ngroups = (p.cout2 + 7) >> 3;   // register quads that hold real channels
-    unsigned rd[3][P::KC];  // as in the first layer
+    unsigned rd[3][P::KC];  // as in the first layer, based at the mid ring
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int px = 32 * pg + pl + kx;
 #pragma unroll
-        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+        for (int kr = 0; kr < P::KC; ++kr)
+            rd[kx][kr] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
     }
     const int H = p.h, W = p.w;
     bf16x8 bq[2][P::KC];
@@ -636,18 +694,15 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
         const int jq = 32 * pg + pl, xq = x0 + jq;   // output column within the strip / the image
         const bool col_ok = jq < P::TWO && xq < W;
 
-        auto row_body = [&](auto par_c, const int o) {
-            constexpr int PAR = decltype(par_c)::value;
+        auto row_body = [&](auto q_c, const int o) {
+            constexpr int Q = decltype(q_c)::value;   // o mod NY: compile-time mid-ring slots, as in pair_second_layer
+            constexpr int PAR = Q & 1;
             const int y = y0 + o;
-            unsigned rowa[3];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-                rowa[ky] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(((o + ky) & (P::NY - 1)) * P::SLOT_BYTES);
-            if constexpr (PAR == 0) {
+            if constexpr (Q == 0) {
                 if (o == 0) {
                     static_for<0, P::KC>([&](auto kc_c) {
                         constexpr int kc = decltype(kc_c)::value;
-                        bq[0][kc] = lds_read_b128(rowa[0] + rd[0][kc]);
+                        bq[0][kc] = lds_read_b128_off<0>(rd[0][kc]);
                     });
                     lds_wait<0>();
                     static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
@@ -665,7 +720,7 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
                     SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg);
                     constexpr int kc = decltype(kc_c)::value;
                     mfma_pinned<true, (t == 0 && kc == 0), 0>(acc, wreg[t][kc], bq[cur][kc]);
-                    bq[nxt][kc] = lds_read_b128(rowa[kyn] + rd[tn % 3][kc]);   // fragment kc of the next tap
+                    bq[nxt][kc] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kc]);   // fragment kc of the next tap
                 });
             });
             asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc));   // MFMA result -> the reads below
@@ -692,13 +747,14 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
         __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
         const int nsteps = nout + P::LAG;
 #pragma unroll 1
-        for (int s = 0; s < nsteps; s += 2) {
-            __builtin_amdgcn_s_barrier();
-            if (s >= P::LAG) row_body(IntC<0>{}, s - P::LAG);
-            if (s + 1 < nsteps) {
-                __builtin_amdgcn_s_barrier();
-                if (s + 1 >= P::LAG) row_body(IntC<1>{}, s + 1 - P::LAG);
-            }
+        for (int s = 0; s < nsteps; s += P::NY) {
+            static_for<0, P::NY>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+                if (Q == 0 || s + Q < nsteps) {
+                    __builtin_amdgcn_s_barrier();
+                    if (s + Q >= P::LAG) row_body(q_c, s + Q - P::LAG);
+                }
+            });
         }
     }
 }
