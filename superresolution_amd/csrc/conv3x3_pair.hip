@@ -548,6 +548,14 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                 }
             }
 
+            // Schedule of the row (previous row = o - 1, whose accumulators sit in the staging buffer / in acc[1]):
+            //   tap 0   MFMAs in tile-major order (tile 0's four, then tile 1's); the gaps behind the first four hand the
+            //           previous row's tile-1 accumulator to the staging buffer before MFMA 4 starts to overwrite it
+            //   tap 8   tile-major again; the gaps behind MFMAs 4..7 stage THIS row's tile-0 accumulator, complete since
+            //           MFMA 3: no accumulator is staged outside the MFMA stream, a row ends without a drain
+            //   odd taps 1..7, gap 0     staging read-back of store group (t - 1) / 2 of the previous row
+            //   even taps 0..6, gap 0    residual read t / 2 of this row
+            //   taps 2k+2, 2k+3 (k < 3)  channels 0..3 / 4..7 + store of group k;  tap 8: all of group 3
             static_for<0, 9>([&](auto t_c) {
                 SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
                 SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
@@ -555,37 +563,46 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                 constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
                 constexpr int tn = (t + 1) % 9;
                 constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
-                constexpr int KG = (t - 1) / 2;                 // store group served by taps 2k+1, 2k+2
-                constexpr bool EPI = t >= 1 && KG < P::NST;
-                lds_wait<0>();
-                if constexpr (EPI && (t & 1)) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
-                if constexpr (t >= 2 && t % 2 == 0 && t / 2 <= NRES) SRHIP_LOAD_FENCE(resv[PAR][t / 2 - 1]);   // read in gap 0 of the previous tap
+                constexpr int KG = t == 8 ? P::NST - 1 : (t - 2) / 2;   // store group whose arithmetic runs in this tap
+                constexpr bool EPI = t >= 2;
+                constexpr bool TILE_MAJOR = t == 0 || t == 8;
+                // tap 0 needs only its fragments, fenced at the end of the previous row; the staging writes issued
+                // in tap 8 may still be in flight
+                if constexpr (t >= 1) lds_wait<0>();
+                if constexpr (EPI && t % 2 == 0 && t < 8) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
+                if constexpr (t == 8) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
+                if constexpr (t % 2 == 1 && t / 2 < NRES) SRHIP_LOAD_FENCE(resv[PAR][t / 2]);   // read in gap 0 of the previous tap
                 static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
 
-                constexpr int ESTEPS = !EPI ? 0 : ((t & 1) ? 4 : 5);
+                constexpr int ESTEPS = !EPI ? 0 : (t == 8 ? 9 : ((t & 1) ? 5 : 4));
                 constexpr int NS = ESTEPS;
                 static_for<0, P::MPT>([&](auto m_c) {
                     SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
                     SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
                     constexpr int ml = decltype(m_c)::value;
-                    constexpr int kc = ml / P::NCT, ct = ml % P::NCT;
+                    constexpr int kc = TILE_MAJOR ? ml % P::KC : ml / P::NCT;
+                    constexpr int ct = TILE_MAJOR ? ml / P::KC : ml % P::NCT;
                     constexpr int f = (t * P::KC + kc) * P::NCT + ct;
                     mfma_pinned<(f < P::NFA2), (t == 0 && kc == 0), ct>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
-                    // gap 0: staging read-back of a store group of the previous row (even taps) or one residual read of
-                    // this row (odd taps); gaps 1..KC: pixel fragments of the next tap.  Every LDS read is issued early
-                    // in its tap, so the wait at the top of the next tap finds it complete.
-                    if constexpr (ml == 0 && (t % 2 == 0) && (t / 2 < P::NST)) epi_read(IntC<t / 2 + 0 * ml>{});
-                    if constexpr (ml == 0 && (t % 2 == 1) && (t / 2 < NRES)) resv[PAR][t / 2] = lds_read_u32x4(xrow + rres[t / 2]);
+                    // Every LDS read is issued early in its tap, so the wait at the top of the next tap finds it complete.
+                    if constexpr (ml == 0 && (t % 2 == 1) && (t / 2 < P::NST)) epi_read(IntC<t / 2 + 0 * ml>{});
+                    if constexpr (ml == 0 && (t % 2 == 0) && (t / 2 < NRES)) resv[PAR][t / 2] = lds_read_u32x4(xrow + rres[t / 2]);
                     if constexpr (ml >= 1 && ml <= P::KC) {
                         constexpr int kr = ml - 1;
                         bq[nxt][kr] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kr]);
                     }
+                    // accumulator quads -> staging (behind the tap's LDS reads: the end-of-row wait counts on that)
+                    if constexpr (t == 0 && ml < 4) lds_write_acc_quad<1, ml>(wst ^ (unsigned)((8 + 2 * ml) << 4), acc[1]);
+                    if constexpr (t == 8 && ml >= 4) lds_write_acc_quad<0, ml - 4>(wst ^ (unsigned)((2 * (ml - 4)) << 4), acc[0]);
                     static_for<ml * NS / P::MPT, (ml + 1) * NS / P::MPT>([&](auto s_c) {
                         SRHIP_CAPTURE(resv); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
                         constexpr int S = decltype(s_c)::value;
                         if constexpr (S < ESTEPS) {
                             constexpr int KD = KG + 0 * S;
-                            if constexpr (t & 1) {
+                            if constexpr (t == 8) {
+                                if constexpr (S < 8) epi_elem(IntC<KD>{}, IntC<S + 0 * KD>{}, IntC<PAR ^ 1>{});
+                                else epi_store(IntC<KD>{}, st_soff);
+                            } else if constexpr (t % 2 == 0) {
                                 epi_elem(IntC<KD>{}, IntC<S + 0 * KD>{}, IntC<PAR ^ 1>{});
                             } else {
                                 if constexpr (S < 4) epi_elem(IntC<KD>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
@@ -593,17 +610,11 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                             }
                         }
                     });
-                    if constexpr (NS > 0) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (NS > 0 || TILE_MAJOR) __builtin_amdgcn_sched_barrier(0);
                 });
             });
-
-            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]), "+" SRHIP_ACC_REG1(acc[1]));
-            static_for<0, 4 * P::NCT>([&](auto s_c) {
-                constexpr int S = decltype(s_c)::value;
-                constexpr int ct = S / 4, g = S % 4;
-                lds_write_acc_quad<ct, g>(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);
-            });
-            lds_wait<4 * P::NCT>();
+            // in flight across the end of the row: only tap 8's four staging writes (issued behind its fragment reads)
+            lds_wait<4>();
             static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
         };
 
@@ -621,8 +632,14 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                 }
             });
         }
-        // drain: second epilogue half of the last row
+        // drain: the last row's tile-1 accumulator goes to the staging buffer (no next row does it), then its epilogue
         {
+            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG1(acc[1]));   // MFMA result -> LDS data read
+            static_for<0, 4>([&](auto g_c) {
+                SRHIP_CAPTURE(acc);
+                constexpr int g = decltype(g_c)::value;
+                lds_write_acc_quad<1, g>(wst ^ (unsigned)((8 + 2 * g) << 4), acc[1]);
+            });
             const unsigned st_soff = (unsigned)(y0 + nout - 1) * row_pitch;
             auto tail = [&](auto ap_c) {
                 static_for<0, P::NST>([&](auto k_c) {

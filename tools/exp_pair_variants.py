@@ -50,6 +50,11 @@ def build(only=None, rev=None):
     if rev:
         old = subprocess.check_output(["git", "-C", ROOT, "show", f"{rev}:superresolution_amd/csrc/conv3x3_pair.hip"], text=True)
         todo[f"rev_{rev}"] = old
+    flags = {}
+    for name in list(todo):
+        if os.environ.get("EXP_SLP"):       # the same variant with the SLP vectoriser left on (packed fp32 beside MFMAs)
+            todo[name + "_slp"] = todo[name]
+            flags[name + "_slp"] = ["-fslp-vectorize"]
     for name, patches in todo.items():
         text = src
         if isinstance(patches, str):
@@ -62,8 +67,8 @@ def build(only=None, rev=None):
         with open(path, "w") as f:
             f.write(text)
         so = os.path.join(OUT, f"libpair_{name}.so")
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-shared",
-               "-no-hip-rt", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable", path, os.path.join(CSRC, "runtime.hip"), "-o", so]
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-shared",
+               "-no-hip-rt", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable", *flags.get(name, []), path, os.path.join(CSRC, "runtime.hip"), "-o", so]
         print("building", name, flush=True)
         subprocess.check_call(cmd)
         os.remove(path)
