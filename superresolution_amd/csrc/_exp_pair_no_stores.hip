@@ -1,0 +1,873 @@
+// Two chained 3x3 / stride 1 / pad 1 convolutions of a 64-channel residual block as ONE kernel for gfx950:
+//
+//     mid = ReLU(conv1(x) + b1)                       (never leaves the chip unless the caller asks for it)
+//     dst = alpha * act2(conv2(mid) + b2) + x
+//
+// i.e. SRResidualBlock (act2 none, alpha 0.2) and Residual(ConvActivation, ConvActivation) (act2 ReLU, alpha 1) of the
+// reference's default network.  As two launches the pair moves 128 + 128 (first layer) + 128 + 128 + 128 (second
+// layer with its residual) = 640 bytes of HBM traffic per pixel; fused it reads x once and writes dst once: 256.
+//
+// Structure: the streaming implicit GEMM of conv3x3_mfma.hip (one wave per SIMD, a layer's whole weight tensor pinned
+// in the wave's registers, input rows flowing HBM -> LDS by LDS-DMA a few rows ahead, v_mfma_f32_32x32x16_bf16 with
+// A = weights and B = 32 pixels), with the four waves of a workgroup SPECIALISED: waves 0-1 hold the first layer's
+// weights and produce rows of `mid` for 64 columns into an LDS ring (bias through the accumulator's initial value,
+// ReLU and the zero padding of `mid` outside the image applied on packed bf16 pairs, written pixel-major with the same
+// XOR swizzle the LDS-DMA gives the x rows); waves 2-3 hold the second layer's weights, read `mid` rows from that ring
+// exactly as the first layer reads x rows, and run the single-layer kernel's epilogue (fp32 staging through LDS,
+// bias / alpha / activation / residual, 16-byte whole-pixel stores).  The second layer runs four rows behind the first:
+// one barrier per row step hands a finished `mid` row over.  A strip yields 62 output columns (the first layer
+// computes the 64 `mid` columns they need, from 66 columns of x); a vertical segment of R rows costs R + 2 rows of
+// first-layer work.
+//
+// Every vector-memory operation and every LDS read is asm with a COUNTED wait, as in the single-layer kernel; the same
+// fence discipline applies (tools/isa_lint.py checks it).
+#include <atomic>
+
+#include "conv_mfma_util.h"
+#include "srhip_common.h"
+
+namespace {
+
+struct PairParams {
+    const char* src;
+    const bf16x8* wpack1;
+    const float* bias1;
+    const bf16x8* wpack2;
+    const float* bias2;
+    char* mid;
+    char* dst;
+    int n, h, w;
+    float slope2, alpha;
+    int nstrips, nsegs, seg_h, total_items;
+    int cout2;   // head form: output channels (1..32) of the second layer, written as fp32 NCHW planes
+};
+
+struct PairCfg {
+    static constexpr int CH = 64;                      // channels of x, mid and dst
+    static constexpr int KC = 4, NCT = 2;              // 16-channel K planes, 32-wide output-channel tiles
+    static constexpr int MPT = KC * NCT;               // MFMAs per tap
+    static constexpr int TWO = 62;                     // output columns per strip
+    static constexpr int XPX = 66;                     // x columns per row held in LDS (mid: 64)
+    static constexpr int PITCH = 72;                   // pixels per LDS row image (whole 1-KiB pieces)
+    static constexpr int SLOT_BYTES = PITCH * CH * 2;  // 9216
+    static constexpr int NPIECE = SLOT_BYTES / 1024;   // 9 LDS-DMA pieces per x row
+    static constexpr int MAXP = 5;                     // pieces per first-layer wave per row (wave w: w, w+2, ..., w+8)
+    static constexpr int LA = 5;                       // x rows fetched ahead of the row being computed
+    static constexpr int RING = 8;                     // x row slots: rows s-2 (the second layer's residual) .. s+LA in step s
+    static constexpr int NY = 4;                       // mid row slots
+    static constexpr int LAG = 4;                      // the second layer computes output row s - LAG in step s
+    static constexpr int XRING_BYTES = RING * SLOT_BYTES;
+    static constexpr int YRING_OFF = XRING_BYTES;
+    static constexpr int YRING_BYTES = NY * SLOT_BYTES;
+    // second layer: epilogue staging as in the single-layer kernel (32 px x 64 fp32 per wave)
+    static constexpr int NSLOT = 8 * NCT, PXS = NSLOT * 16, LPP = NSLOT / 2, PPI = 64 / LPP, NST = 2 * NCT;
+    static constexpr int STAGE_OFF = YRING_OFF + YRING_BYTES;
+    static constexpr int STAGE_BYTES = 32 * PXS;
+    static constexpr int DUMMY_OFF = STAGE_OFF + 2 * STAGE_BYTES;  // 1 KiB sink of the one DMA piece nobody owns
+    static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
+    static constexpr int NFA1 = 256 / 4;               // first layer: accumulators in VGPRs, 64 fragments in AGPRs
+    static constexpr int NFA2 = (256 - 16 * NCT) / 4;  // second layer: accumulators a[0:31], 56 fragments in AGPRs
+};
+
+// MFMA of the first layer: accumulator in VGPRs (the epilogue's vector ALU reads it directly); the first MFMA of a
+// row's chain takes the bias (accumulator order) as C.
+template <bool IN_AGPR, bool FIRST>
+__device__ __forceinline__ void mfma_vacc(f32x16& acc, const bf16x8& w, const bf16x8& b, const f32x16& cinit)
+{
+    if constexpr (IN_AGPR) {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w), "v"(b), "v"(cinit));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+    } else {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(w), "v"(b), "v"(cinit));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+    }
+}
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// ReLU on a packed pair of bf16 values: a negative bf16 is a negative int16, so max(., 0) per half clears it.
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned v)
+{
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64_off(unsigned addr, unsigned lo, unsigned hi)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    const unsigned long long d = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(d), "n"(OFF) : "memory");
+}
+// addr ^ (C << 4) as an instruction the optimiser cannot hoist: with compile-time ring slots the 8 swizzled write
+// addresses of a row are loop invariants, and 8 more live registers do not exist in the first-layer waves.
+template <int C, bool OPAQUE>
+__device__ __forceinline__ unsigned xor_slot16(unsigned addr)
+{
+    if constexpr (!OPAQUE) return addr ^ (unsigned)(C << 4);
+    unsigned r;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "n"(C << 4), "v"(addr));
+    return r;
+}
+__device__ __forceinline__ u32x4 lds_read_u32x4(unsigned addr)
+{
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+// Fragment read whose ring slot enters through the instruction's 16-bit offset field: the row loops are unrolled over
+// the ring (8 x rows, 4 mid rows), so the slot of every read is a compile-time constant and no address arithmetic runs
+// per read (one vector add per fragment otherwise: 36 per row and wave).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_u32x4_off(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128_off(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// slot offset in the instruction (IMM) or added to the address
+template <bool IMM, int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128_sel(unsigned dyn_off, unsigned addr)
+{
+    if constexpr (IMM) return lds_read_b128_off<OFF>(addr);
+    else return lds_read_b128(dyn_off + addr);
+}
+
+struct PairItem {
+    int n, x0, y0, nout;
+};
+__device__ __forceinline__ PairItem pair_decode_item(const PairParams& p, int item)
+{
+    const int strip = item % p.nstrips;
+    const int tseg = item / p.nstrips;
+    const int seg = tseg % p.nsegs;
+    PairItem it;
+    it.n = tseg / p.nsegs;
+    it.x0 = strip * PairCfg::TWO;
+    it.y0 = seg * p.seg_h;
+    it.nout = min(it.y0 + p.seg_h, p.h) - it.y0;
+    return it;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Waves 0-1: first layer.  Step s computes mid row s (image row y0 - 1 + s) for the 32 columns x0 - 1 + 32 pg + pl from
+// x rows s .. s+2 of the ring; the row's epilogue (accumulators -> bf16 -> LDS) runs between the MFMAs of step s + 1.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool STORE_MID>
+__device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
+                                                 const int lane)
+{
+    using P = PairCfg;
+    const int hl = lane >> 5, pl = lane & 31;
+    constexpr bool IMM = !STORE_MID;               // compile-time ring slots (see `step`)
+    constexpr int UNR = IMM ? P::RING : 2;         // copies of the row loop's body
+    // vector-memory schedule of one step: taps 0..3 [mid store of row s-2 (STORE_MID)] [DMA piece t of x row s+LA],
+    // tap 4 [DMA piece 4]; the last DMA is the last operation of the step.
+    constexpr int VM_STEP = P::MAXP + (STORE_MID ? 4 : 0);
+    constexpr int WAIT_STEADY = (P::LA - 3) * VM_STEP;                 // row s+2 was issued in step s+2-LA
+    constexpr int WAIT_EARLY = P::MAXP + VM_STEP < 2 * VM_STEP ? P::MAXP + VM_STEP : 2 * VM_STEP;
+    static_assert(WAIT_STEADY <= 63 && P::LA == 5, "vmcnt is a 6-bit field; the early-step waits assume LA = 5");
+
+    bf16x8 wreg[9][P::KC][P::NCT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kc = 0; kc < P::KC; ++kc)
+#pragma unroll
+            for (int ct = 0; ct < P::NCT; ++ct) wreg[t][kc][ct] = p.wpack1[((t * P::KC + kc) * P::NCT + ct) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // The weight loads must have landed BEFORE the row loop: a wait the compiler leaves at their first use sits between
+    // the MFMAs of every row and drains the hand-counted vector-memory queue there.  An empty asm that "uses" each
+    // fragment (in the register file it is pinned to) makes the compiler place its wait here.
+    static_for<0, 9 * P::KC * P::NCT>([&](auto f_c) {
+        SRHIP_CAPTURE(wreg);
+        constexpr int f = decltype(f_c)::value;
+        if constexpr (f < P::NFA1) asm volatile("" : "+a"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+        else asm volatile("" : "+v"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+    });
+    // bias in accumulator order: register r of tile ct <-> channel 32 ct + 8 (r >> 2) + 4 hl + (r & 3)
+    f32x16 biasv[P::NCT];
+#pragma unroll
+    for (int ct = 0; ct < P::NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            biasv[ct][r] = p.bias1 != nullptr ? p.bias1[ct * 32 + 8 * (r >> 2) + 4 * hl + (r & 3)] : 0.0f;
+
+    // fragment of k-chunk kr for tap column kx: chunk 2 kr + hl of LDS pixel 32 pg + pl + kx (chunk c of pixel px sits at
+    // 16-byte slot c ^ ((px >> 1) & 7)); slot bases are multiples of 1 KiB, so one add per read forms the address
+    unsigned rd[3][P::KC];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = 32 * pg + pl + kx;
+#pragma unroll
+        for (int kr = 0; kr < P::KC; ++kr) rd[kx][kr] = lds_base + (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+    }
+    const int q = 32 * pg + pl;                                             // this lane's mid pixel in the row image
+    // its quad (ct, g) goes to wy ^ ((4 ct + g) << 4) of the row's slot (slot offsets are multiples of 1 KiB: the XOR
+    // of bits 4..6 commutes with adding them, so the slot enters through the write's offset field)
+    const unsigned wy = lds_base + (unsigned)P::YRING_OFF + (unsigned)(q * 128 + 8 * hl + (((q >> 1) & 7) << 4));
+    unsigned rb[4];  // read-back for the mid store: group k = pixels 32 pg + 8 k + (lane >> 3), chunk lane & 7
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int qk = 32 * pg + 8 * k + (lane >> 3);
+        rb[k] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(qk * 128 + (((lane & 7) ^ ((qk >> 1) & 7)) << 4));
+    }
+
+    const int H = p.h, W = p.w;
+    bf16x8 bq[2][P::KC];
+    f32x16 acc[2][P::NCT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ct = 0; ct < P::NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][ct][r] = 0.0f;
+    u32x4 midv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) midv[k] = u32x4{0u, 0u, 0u, 0u};
+    unsigned e_p0 = 0, e_p1 = 0, e_addr = 0;
+
+    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+        const PairItem it = pair_decode_item(p, item);
+        const int x0 = it.x0, y0 = it.y0, nout = it.nout;
+        const int nin = nout + 4;  // x rows rx = 0..nin-1 <-> image row y0 - 2 + rx
+        const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
+        const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
+        const __amdgpu_buffer_rsrc_t rsrc_x =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + (long long)it.n * img), 0, (int)img, 0x00020000);
+        const i32x4 mid_srd = make_srd(STORE_MID ? p.mid + (long long)it.n * img : p.dst, STORE_MID ? img : 0u);
+
+        unsigned poff[P::MAXP];
+#pragma unroll
+        for (int m = 0; m < P::MAXP; ++m) {
+            const int piece = pg + 2 * m;
+            const int j = piece * 64 + lane;
+            const int px = j >> 3;
+            const int c = (j & 7) ^ ((px >> 1) & 7);
+            const int x = x0 - 2 + px;
+            const bool ok = (x >= 0) && (x < W) && (px < P::XPX) && (piece < P::NPIECE);
+            poff[m] = ok ? (unsigned)((x * P::CH + c * 8) * 2) : kOobOffset;
+        }
+        const int ycol = x0 - 1 + q;
+        const unsigned colmask = (ycol >= 0 && ycol < W) ? 0xffffffffu : 0u;
+        unsigned mvo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int qk = 32 * pg + 8 * k + (lane >> 3);
+            const int col = x0 - 1 + qk;
+            mvo[k] = (STORE_MID && qk >= 1 && qk <= P::TWO && col < W) ? (unsigned)((col * P::CH + (lane & 7) * 8) * 2) : kOobOffset;
+        }
+
+        auto issue_piece = [&](auto m_c, const unsigned soff, const unsigned slot_off) {
+            constexpr int m = decltype(m_c)::value;
+            const int piece = pg + 2 * m;
+            const bool mine = (m < P::MAXP - 1) || (piece < P::NPIECE);
+            const unsigned off = mine ? slot_off + (unsigned)piece * 1024u : (unsigned)P::DUMMY_OFF;
+            lds_dma_b128(rsrc_x, (__attribute__((address_space(3))) void*)(smem + off), poff[m], soff);
+        };
+        auto row_soff = [&](const int rx) -> unsigned {
+            const int y = y0 - 2 + rx;
+            const bool yin = (y >= 0) & (y < H) & (rx < nin);
+            return yin ? (unsigned)y * row_pitch : kOobOffset;
+        };
+        // epilogue of one accumulator quad: four consecutive channels of this lane's pixel -> bf16, ReLU, padding mask
+        auto quad_pack = [&](const f32x16& a, auto g_c, const unsigned ymask, unsigned& o0, unsigned& o1) {
+            constexpr int g = decltype(g_c)::value;
+            o0 = relu_bf16x2(pack_bf16x2(a[4 * g + 0], a[4 * g + 1])) & ymask;
+            o1 = relu_bf16x2(pack_bf16x2(a[4 * g + 2], a[4 * g + 3])) & ymask;
+        };
+
+        // IMM (the form that does not store mid): the row loop is unrolled over the x ring, Q = s mod RING, so the slots
+        // of rows s .. s+2 and of mid row s-1 are compile-time constants that enter through the offset field of the LDS
+        // instructions.  The form that stores mid has no registers left for eight copies of the loop body's live ranges:
+        // it is unrolled over the row parity only (Q = s mod 2) and adds the slot offsets per access.
+        auto step = [&](auto q_c, const int s) {
+            constexpr int Q = decltype(q_c)::value;
+            constexpr int PAR = Q & 1;
+            const bool compute = s < nout + 2;
+            if (compute) {
+                if (s == 0) vm_wait<0>();
+                else if (s < P::LA - 2) vm_wait<WAIT_EARLY>();
+                else vm_wait<WAIT_STEADY>();
+            }
+            __builtin_amdgcn_s_barrier();
+
+            // mid row s-1 (accumulators of the other parity) goes to slot (s-1) & 3; rows outside the image are zeros
+            const int yr = s - 1;
+            const int yimg = y0 - 1 + yr;
+            // offset of slot (s - 1) mod NY: in the instruction (IMM) or added to the address registers
+            constexpr int YSLOT = IMM ? ((Q + P::NY - 1) & (P::NY - 1)) * P::SLOT_BYTES : 0;
+            const unsigned yslot_dyn = IMM ? 0u : (unsigned)((yr & (P::NY - 1)) * P::SLOT_BYTES);
+            const unsigned wys = wy + yslot_dyn;
+            unsigned rowx[3];   // !IMM: x-ring slot offsets of rows s .. s+2
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) rowx[ky] = IMM ? 0u : (unsigned)(((s + ky) & (P::RING - 1)) * P::SLOT_BYTES);
+            const unsigned ymask = (s >= 1 && yimg >= 0 && yimg < H) ? colmask : 0u;
+            // mid row s-2 (read back at the end of step s-1) goes to HBM if it is one of the segment's own rows
+            const int mr = s - 2;
+            const unsigned mid_soff = (mr >= 1 && mr <= nout) ? (unsigned)(y0 - 1 + mr) * row_pitch : kOobOffset;
+
+            if (!compute) {
+                if (s == nout + 2) {
+                    // the last mid row's epilogue and the last mid store, with nothing to hide them behind
+                    static_for<0, 8>([&](auto t_c) {
+                        SRHIP_CAPTURE(acc);
+                        constexpr int t = decltype(t_c)::value;
+                        unsigned o0, o1;
+                        quad_pack(acc[PAR ^ 1][t / 4], IntC<t % 4>{}, ymask, o0, o1);
+                        lds_write_b64_off<YSLOT>(xor_slot16<4 * (t / 4) + (t % 4), IMM>(wys), o0, o1);
+                    });
+                    if constexpr (STORE_MID) {
+                        static_for<0, 4>([&](auto k_c) {
+                            SRHIP_CAPTURE(midv);
+                            buffer_store_b128_guarded(midv[decltype(k_c)::value], mid_srd, mvo[decltype(k_c)::value], mid_soff);
+                        });
+                    }
+                    lds_wait<0>();
+                }
+                return;
+            }
+
+            const unsigned dma_soff = row_soff(s + P::LA);
+            const unsigned dma_slot = (unsigned)(((s + P::LA) & (P::RING - 1)) * P::SLOT_BYTES);
+
+            if constexpr (Q == 0) {
+                if (s == 0) {  // first row of the item: nobody fetched its tap 0 yet
+                    static_for<0, P::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[0][kc] = lds_read_b128_sel<IMM, 0>(rowx[0], rd[0][kc]);
+                    });
+                    lds_wait<0>();
+                    static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
+                }
+            }
+
+            static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(midv); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
+                SRHIP_CAPTURE(e_p0); SRHIP_CAPTURE(e_p1); SRHIP_CAPTURE(e_addr);
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                // this tap's fragments (issued during the previous tap) have landed; the mid write issued BEHIND them may
+                // still be in flight (LDS operations of a wave complete in order)
+                if constexpr (t >= 1) lds_wait<1>();
+                else lds_wait<0>();
+                static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+                static_for<0, P::MPT>([&](auto m_c) {
+                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(midv); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
+                    SRHIP_CAPTURE(e_p0); SRHIP_CAPTURE(e_p1); SRHIP_CAPTURE(e_addr);
+                    constexpr int ml = decltype(m_c)::value;
+                    constexpr int kc = ml / P::NCT, ct = ml % P::NCT;
+                    constexpr int f = (t * P::KC + kc) * P::NCT + ct;
+                    mfma_vacc<(f < P::NFA1), (t == 0 && kc == 0)>(acc[PAR][ct], wreg[t][kc][ct], bq[cur][kc], biasv[ct]);
+                    // gaps 1..KC: pixel fragments of the next tap (tap 8: tap 0 of the next row, whose x rows are resident)
+                    if constexpr (ml >= 1 && ml <= P::KC) {
+                        constexpr int kr = ml - 1;
+                        bq[nxt][kr] = lds_read_b128_sel<IMM, ((Q + kyn) & (P::RING - 1)) * P::SLOT_BYTES>(rowx[kyn], rd[tn % 3][kr]);
+                    }
+                    // taps 0..7: quad t of the previous row's accumulators -> mid ring
+                    if constexpr (t < 8) {
+                        constexpr int qct = t / 4, qg = t % 4;
+                        if constexpr (ml == 0) e_p0 = pack_bf16x2(acc[PAR ^ 1][qct][4 * qg + 0], acc[PAR ^ 1][qct][4 * qg + 1]);
+                        if constexpr (ml == 1) e_p1 = pack_bf16x2(acc[PAR ^ 1][qct][4 * qg + 2], acc[PAR ^ 1][qct][4 * qg + 3]);
+                        if constexpr (ml == 2) e_p0 = relu_bf16x2(e_p0) & ymask;
+                        if constexpr (ml == 3) e_p1 = relu_bf16x2(e_p1) & ymask;
+                        if constexpr (ml == 5) e_addr = xor_slot16<4 * qct + qg, IMM>(wys);
+                        if constexpr (ml == 7) lds_write_b64_off<YSLOT>(e_addr, e_p0, e_p1);
+                    }
+                    if constexpr (STORE_MID && t < 4 && ml == 5)
+                        buffer_store_b128_guarded(midv[t], mid_srd, mvo[t], mid_soff);
+                    if constexpr (t < P::MAXP && ml == 6) issue_piece(IntC<t + 0 * ml>{}, dma_soff, dma_slot);
+                    // tap 8: read the finished mid row (this wave's 32 pixels) back pixel-major for the store in the next step
+                    if constexpr (STORE_MID && t == 8 && ml >= 4) midv[ml - 4] = lds_read_u32x4_off<YSLOT>(yslot_dyn + rb[ml - 4]);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
+                });
+            });
+            // MFMA result -> vector ALU readers of the next step: the hazard is invisible to the compiler inside asm
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[PAR][0]), "+v"(acc[PAR][1]));
+            // nothing stays in flight across the end of a step: next row's tap-0 fragments, the read-back, the mid writes
+            lds_wait<0>();
+            static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
+            if constexpr (STORE_MID) static_for<0, 4>([&](auto k_c) { SRHIP_CAPTURE(midv); SRHIP_LOAD_FENCE(midv[decltype(k_c)::value]); });
+        };
+
+        __builtin_amdgcn_s_barrier();  // every wave is done with the previous item's LDS rows
+#pragma unroll 1
+        for (int r = 0; r < P::LA; ++r) {
+            const unsigned so = row_soff(r);
+            static_for<0, P::MAXP>([&](auto m_c) { issue_piece(m_c, so, (unsigned)(r * P::SLOT_BYTES)); });
+        }
+        const int nsteps = nout + P::LAG;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += UNR) {
+            if constexpr (UNR == 2) {
+                step(IntC<0>{}, s);
+                if (s + 1 < nsteps) step(IntC<1>{}, s + 1);
+            } else {
+                static_for<0, UNR>([&](auto q_c) {
+                    constexpr int Q = decltype(q_c)::value;
+                    if (Q == 0 || s + Q < nsteps) step(q_c, s + Q);
+                });
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Waves 2-3: second layer.  Step s computes output row o = s - LAG (image row y0 + o) for the columns x0 + 32 pg + pl
+// from mid rows o .. o+2 of the ring; epilogue as in the single-layer kernel with the residual form.
+// ------------------------------------------------------------------------------------------------------------------
+// ACT2: activation of the second layer known at compile time (0 none, 1 ReLU, 2 LeakyReLU): its epilogue is the wave's
+// critical vector-ALU work, and the common forms need fewer instructions than max(t, slope * t).
+template <int ACT2>
+__device__ __forceinline__ void pair_second_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
+                                                  const int lane)
+{
+    using P = PairCfg;
+    const int hl = lane >> 5, pl = lane & 31;
+    // The residual (x at the output pixel) is still in the x ring: four pixel-major LDS reads per row replace a second
+    // trip to memory.  The only vector-memory operations of these waves are the output stores: nothing to wait for.
+    constexpr int NRES = P::NST;
+
+    bf16x8 wreg[9][P::KC][P::NCT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kc = 0; kc < P::KC; ++kc)
+#pragma unroll
+            for (int ct = 0; ct < P::NCT; ++ct) wreg[t][kc][ct] = p.wpack2[((t * P::KC + kc) * P::NCT + ct) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<0, 9 * P::KC * P::NCT>([&](auto f_c) {   // the loads land before the row loop: see the first layer
+        SRHIP_CAPTURE(wreg);
+        constexpr int f = decltype(f_c)::value;
+        if constexpr (f < P::NFA2) asm volatile("" : "+a"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+        else asm volatile("" : "+v"(wreg[f / (P::KC * P::NCT)][(f / P::NCT) % P::KC][f % P::NCT]));
+    });
+    // store-time lane roles: lane = (pixel st_q of a group of 8 pixels, 8-channel chunk st_c)
+    const int st_q = lane / P::LPP, st_c = lane % P::LPP;
+    const int st_fw = pl & 15;
+    const unsigned stage_lds = lds_base + (unsigned)P::STAGE_OFF + (unsigned)(pg * P::STAGE_BYTES);
+    const unsigned wst = stage_lds + (unsigned)(pl * P::PXS) + (unsigned)(((hl ^ st_fw) & (P::NSLOT - 1)) << 4);
+    unsigned rdst[P::NST];
+#pragma unroll
+    for (int k = 0; k < P::NST; ++k) {
+        const int qq = k * P::PPI + st_q;
+        rdst[k] = stage_lds + (unsigned)(qq * P::PXS) + (unsigned)((((2 * st_c) ^ (qq & 15)) & (P::NSLOT - 1)) << 4);
+    }
+    float breg[8];  // alpha * bias of this lane's 8 store-time channels
+#pragma unroll
+    for (int r = 0; r < 8; ++r) breg[r] = (p.bias2 != nullptr ? p.bias2[st_c * 8 + r] : 0.0f) * p.alpha;
+    unsigned rd[3][P::KC];  // as in the first layer, based at the mid ring
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = 32 * pg + pl + kx;
+#pragma unroll
+        for (int kr = 0; kr < P::KC; ++kr)
+            rd[kx][kr] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+    }
+    unsigned rres[NRES];  // residual of store group k: x-ring pixel 2 + 32 pg + 8 k + st_q (output column + 2), chunk st_c
+#pragma unroll
+    for (int k = 0; k < NRES; ++k) {
+        const int px = 2 + 32 * pg + k * P::PPI + st_q;
+        rres[k] = (unsigned)(px * 128 + ((st_c ^ ((px >> 1) & 7)) << 4));
+    }
+
+    const int H = p.h, W = p.w;
+    bf16x8 bq[2][P::KC];
+    f32x16 acc[P::NCT];
+    u32x4 resv[2][NRES];
+    f32x4 e_lo[2], e_hi[2];
+    float ev[8];
+
+    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+        const PairItem it = pair_decode_item(p, item);
+        const int x0 = it.x0, y0 = it.y0, nout = it.nout;
+        const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
+        const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
+        const i32x4 dst_srd = make_srd(p.dst + (long long)it.n * img, img);
+        unsigned vox[P::NST];
+#pragma unroll
+        for (int k = 0; k < P::NST; ++k) {
+            const int jq = 32 * pg + k * P::PPI + st_q;   // output column within the strip
+            const int xq = x0 + jq;
+            vox[k] = (jq < P::TWO && xq < W) ? (unsigned)((xq * P::CH + st_c * 8) * 2) : kOobOffset;
+        }
+
+        auto epi_read = [&](auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            e_lo[k & 1] = lds_read_f32x4(rdst[k]);
+            e_hi[k & 1] = lds_read_f32x4(rdst[k] ^ 16u);
+        };
+        auto epi_elem = [&](auto k_c, auto e_c, auto ap_c) {
+            constexpr int k = decltype(k_c)::value;
+            constexpr int e = decltype(e_c)::value;
+            constexpr int AP = decltype(ap_c)::value;
+            const float x = e < 4 ? e_lo[k & 1][e & 3] : e_hi[k & 1][e & 3];
+            const float t = fmaf(x, p.alpha, breg[e]);
+            const unsigned rr = resv[AP][k][e >> 1];
+            const float rv = (e & 1) ? bf16_hi(rr) : bf16_lo(rr);
+            if constexpr (ACT2 == 0) ev[e] = t + rv;
+            else if constexpr (ACT2 == 1) ev[e] = fmaxf(t, 0.0f) + rv;
+            else ev[e] = fmaxf(t, t * p.slope2) + rv;
+        };
+        auto epi_store = [&](auto k_c, const unsigned store_soff) {
+            constexpr int k = decltype(k_c)::value;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
+            asm volatile("" :: "v"(o));
+        };
+
+        // One output row.  Q = o mod NY fixes the mid-ring slots of rows o .. o+2 (compile-time fragment addresses);
+        // PAR = o & 1 selects the fragment buffer that holds tap 0 and the residual set.
+        auto row_body = [&](auto q_c, const int o) {
+            constexpr int Q = decltype(q_c)::value;
+            constexpr int PAR = Q & 1;
+            const int y = y0 + o;
+            const unsigned xrow = lds_base + (unsigned)(((o + 2) & (P::RING - 1)) * P::SLOT_BYTES);  // x row of this output row
+            const unsigned st_soff = o > 0 ? (unsigned)(y - 1) * row_pitch : kOobOffset;
+
+            if constexpr (Q == 0) {
+                if (o == 0) {
+                    static_for<0, P::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[0][kc] = lds_read_b128_off<0>(rd[0][kc]);
+                    });
+                    lds_wait<0>();
+                    static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
+                }
+            }
+
+            // Schedule of the row (previous row = o - 1, whose accumulators sit in the staging buffer / in acc[1]):
+            //   tap 0   MFMAs in tile-major order (tile 0's four, then tile 1's); the gaps behind the first four hand the
+            //           previous row's tile-1 accumulator to the staging buffer before MFMA 4 starts to overwrite it
+            //   tap 8   tile-major again; the gaps behind MFMAs 4..7 stage THIS row's tile-0 accumulator, complete since
+            //           MFMA 3: no accumulator is staged outside the MFMA stream, a row ends without a drain
+            //   odd taps 1..7, gap 0     staging read-back of store group (t - 1) / 2 of the previous row
+            //   even taps 0..6, gap 0    residual read t / 2 of this row
+            //   taps 2k+2, 2k+3 (k < 3)  channels 0..3 / 4..7 + store of group k;  tap 8: all of group 3
+            static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                constexpr int KG = t == 8 ? P::NST - 1 : (t - 2) / 2;   // store group whose arithmetic runs in this tap
+                constexpr bool EPI = t >= 2;
+                constexpr bool TILE_MAJOR = t == 0 || t == 8;
+                // tap 0 needs only its fragments, fenced at the end of the previous row; the staging writes issued
+                // in tap 8 may still be in flight
+                if constexpr (t >= 1) lds_wait<0>();
+                if constexpr (EPI && t % 2 == 0 && t < 8) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
+                if constexpr (t == 8) { SRHIP_LOAD_FENCE(e_lo[KG & 1]); SRHIP_LOAD_FENCE(e_hi[KG & 1]); }
+                if constexpr (t % 2 == 1 && t / 2 < NRES) SRHIP_LOAD_FENCE(resv[PAR][t / 2]);   // read in gap 0 of the previous tap
+                static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+
+                constexpr int ESTEPS = !EPI ? 0 : (t == 8 ? 9 : ((t & 1) ? 5 : 4));
+                constexpr int NS = ESTEPS;
+                static_for<0, P::MPT>([&](auto m_c) {
+                    SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
+                    SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                    constexpr int ml = decltype(m_c)::value;
+                    constexpr int kc = TILE_MAJOR ? ml % P::KC : ml / P::NCT;
+                    constexpr int ct = TILE_MAJOR ? ml / P::KC : ml % P::NCT;
+                    constexpr int f = (t * P::KC + kc) * P::NCT + ct;
+                    mfma_pinned<(f < P::NFA2), (t == 0 && kc == 0), ct>(acc[ct], wreg[t][kc][ct], bq[cur][kc]);
+                    // Every LDS read is issued early in its tap, so the wait at the top of the next tap finds it complete.
+                    if constexpr (ml == 0 && (t % 2 == 1) && (t / 2 < P::NST)) epi_read(IntC<t / 2 + 0 * ml>{});
+                    if constexpr (ml == 0 && (t % 2 == 0) && (t / 2 < NRES)) resv[PAR][t / 2] = lds_read_u32x4(xrow + rres[t / 2]);
+                    if constexpr (ml >= 1 && ml <= P::KC) {
+                        constexpr int kr = ml - 1;
+                        bq[nxt][kr] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kr]);
+                    }
+                    // accumulator quads -> staging (behind the tap's LDS reads: the end-of-row wait counts on that)
+                    if constexpr (t == 0 && ml < 4) lds_write_acc_quad<1, ml>(wst ^ (unsigned)((8 + 2 * ml) << 4), acc[1]);
+                    if constexpr (t == 8 && ml >= 4) lds_write_acc_quad<0, ml - 4>(wst ^ (unsigned)((2 * (ml - 4)) << 4), acc[0]);
+                    static_for<ml * NS / P::MPT, (ml + 1) * NS / P::MPT>([&](auto s_c) {
+                        SRHIP_CAPTURE(resv); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                        constexpr int S = decltype(s_c)::value;
+                        if constexpr (S < ESTEPS) {
+                            constexpr int KD = KG + 0 * S;
+                            if constexpr (t == 8) {
+                                if constexpr (S < 8) epi_elem(IntC<KD>{}, IntC<S + 0 * KD>{}, IntC<PAR ^ 1>{});
+                                else epi_store(IntC<KD>{}, st_soff);
+                            } else if constexpr (t % 2 == 0) {
+                                epi_elem(IntC<KD>{}, IntC<S + 0 * KD>{}, IntC<PAR ^ 1>{});
+                            } else {
+                                if constexpr (S < 4) epi_elem(IntC<KD>{}, IntC<4 + S>{}, IntC<PAR ^ 1>{});
+                                else epi_store(IntC<KD>{}, st_soff);
+                            }
+                        }
+                    });
+                    if constexpr (NS > 0 || TILE_MAJOR) __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            // in flight across the end of the row: only tap 8's four staging writes (issued behind its fragment reads)
+            lds_wait<4>();
+            static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
+        };
+
+        __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
+        const int nsteps = nout + P::LAG;
+        static_assert(P::LAG % P::NY == 0, "the row's ring phase is the step's");
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += P::NY) {
+            // step s + Q: output row s + Q - LAG
+            static_for<0, P::NY>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+                if (Q == 0 || s + Q < nsteps) {
+                    __builtin_amdgcn_s_barrier();
+                    if (s + Q >= P::LAG) row_body(q_c, s + Q - P::LAG);
+                }
+            });
+        }
+        // drain: the last row's tile-1 accumulator goes to the staging buffer (no next row does it), then its epilogue
+        {
+            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG1(acc[1]));   // MFMA result -> LDS data read
+            static_for<0, 4>([&](auto g_c) {
+                SRHIP_CAPTURE(acc);
+                constexpr int g = decltype(g_c)::value;
+                lds_write_acc_quad<1, g>(wst ^ (unsigned)((8 + 2 * g) << 4), acc[1]);
+            });
+            const unsigned st_soff = (unsigned)(y0 + nout - 1) * row_pitch;
+            auto tail = [&](auto ap_c) {
+                static_for<0, P::NST>([&](auto k_c) {
+                    SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                    epi_read(k_c);
+                    lds_wait<0>();
+                    SRHIP_LOAD_FENCE(e_lo[decltype(k_c)::value & 1]);
+                    SRHIP_LOAD_FENCE(e_hi[decltype(k_c)::value & 1]);
+                    static_for<0, 8>([&](auto e_c) { epi_elem(k_c, e_c, ap_c); });
+                    epi_store(k_c, st_soff);
+                });
+            };
+            if ((nout - 1) & 1) tail(IntC<1>{});
+            else tail(IntC<0>{});
+        }
+    }
+}
+
+// Head form of the second layer: 64 -> cout2 <= 32 channels (one MFMA tile), no residual, output fp32 NCHW -- the last two
+// layers of the network (core/models/model.py:111-115: Conv + ReLU -> Conv(64 -> 3)) as one launch.  Half the MFMAs of a
+// 64-channel second layer, so these waves wait for the first layer's most of the time: the launch costs what the first
+// layer alone costs, and the 64-channel map between the two layers never reaches memory.  Same barrier sequence, mid-ring
+// addressing and fragment pipeline as pair_second_layer; the epilogue goes straight from the accumulator to 4-byte plane
+// stores (lane = pixel: 128 contiguous bytes per half-wave and channel).
+template <int ACT2>
+__device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
+                                                const int lane)
+{
+    using P = PairCfg;
+    const int hl = lane >> 5, pl = lane & 31;
+    bf16x8 wreg[9][P::KC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kc = 0; kc < P::KC; ++kc) wreg[t][kc] = p.wpack2[(t * P::KC + kc) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<0, 9 * P::KC>([&](auto f_c) {   // the loads land before the row loop: see the first layer
+        SRHIP_CAPTURE(wreg);
+        constexpr int f = decltype(f_c)::value;
+        asm volatile("" : "+a"(wreg[f / P::KC][f % P::KC]));
+    });
+    // accumulator register r of this lane is output channel 8 (r >> 2) + 4 hl + (r & 3) of pixel pl
+    float breg[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 8 * (r >> 2) + 4 * hl + (r & 3);
+        breg[r] = (p.bias2 != nullptr && co < p.cout2) ? p.bias2[co] : 0.0f;
+    }
+    const int ngroups = (p.cout2 + 7) >> 3;   // register quads that hold real channels
+    unsigned rd[3][P::KC];  // as in the first layer, based at the mid ring
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = 32 * pg + pl + kx;
+#pragma unroll
+        for (int kr = 0; kr < P::KC; ++kr)
+            rd[kx][kr] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(px * 128 + (((2 * kr + hl) ^ ((px >> 1) & 7)) << 4));
+    }
+    const int H = p.h, W = p.w;
+    bf16x8 bq[2][P::KC];
+    f32x16 acc;
+
+    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+        const PairItem it = pair_decode_item(p, item);
+        const int x0 = it.x0, y0 = it.y0, nout = it.nout;
+        const unsigned plane = (unsigned)(H * W) * 4u;
+        const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.dst + (long long)it.n * p.cout2 * plane), 0, (int)((unsigned)p.cout2 * plane), 0x00020000);
+        const int jq = 32 * pg + pl, xq = x0 + jq;   // output column within the strip / the image
+        const bool col_ok = jq < P::TWO && xq < W;
+
+        auto row_body = [&](auto q_c, const int o) {
+            constexpr int Q = decltype(q_c)::value;   // o mod NY: compile-time mid-ring slots, as in pair_second_layer
+            constexpr int PAR = Q & 1;
+            const int y = y0 + o;
+            if constexpr (Q == 0) {
+                if (o == 0) {
+                    static_for<0, P::KC>([&](auto kc_c) {
+                        constexpr int kc = decltype(kc_c)::value;
+                        bq[0][kc] = lds_read_b128_off<0>(rd[0][kc]);
+                    });
+                    lds_wait<0>();
+                    static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(kc_c)::value]); });
+                }
+            }
+            static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg);
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                lds_wait<0>();
+                static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+                static_for<0, P::KC>([&](auto kc_c) {
+                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg);
+                    constexpr int kc = decltype(kc_c)::value;
+                    mfma_pinned<true, (t == 0 && kc == 0), 0>(acc, wreg[t][kc], bq[cur][kc]);
+                    bq[nxt][kc] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kc]);   // fragment kc of the next tap
+                });
+            });
+            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc));   // MFMA result -> the reads below
+            const unsigned soff = (unsigned)(y * W) * 4u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < ngroups) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = 8 * g + 4 * hl + e;
+                        const float t = acc[4 * g + e] + breg[4 * g + e];
+                        float v = t;
+                        if constexpr (ACT2 == 1) v = fmaxf(t, 0.0f);
+                        else if constexpr (ACT2 == 2) v = fmaxf(t, t * p.slope2);
+                        const unsigned vo = (col_ok && co < p.cout2) ? (unsigned)co * plane + (unsigned)xq * 4u : kOobOffset;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v * p.alpha), dst_rsrc, vo, soff, 0);
+                    }
+                }
+            }
+            lds_wait<0>();  // tap 8's fetch of the next row's tap 0: nothing stays in flight across rows
+            static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
+        };
+
+        __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
+        const int nsteps = nout + P::LAG;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += P::NY) {
+            static_for<0, P::NY>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+                if (Q == 0 || s + Q < nsteps) {
+                    __builtin_amdgcn_s_barrier();
+                    if (s + Q >= P::LAG) row_body(q_c, s + Q - P::LAG);
+                }
+            });
+        }
+    }
+}
+
+template <bool STORE_MID, int ACT2, bool HEAD = false>
+__global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    if (wave < 2) pair_first_layer<STORE_MID>(p, smem, lds_base, wave, lane);
+    else if constexpr (HEAD) pair_head_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
+    else pair_second_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
+}
+
+template <bool STORE_MID, int ACT2, bool HEAD = false>
+int launch_pair(PairParams p, hipStream_t stream)
+{
+    using P = PairCfg;
+    static std::atomic<bool> configured_dev[kSrhipMaxDevices];  // per device
+    const int dev = srhip_current_device();
+    if (!configured_dev[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                P::LDS_BYTES) != hipSuccess) {
+            srhip_set_error("conv3x3_pair: cannot raise the dynamic LDS limit to %d", P::LDS_BYTES);
+            return SRHIP_ERR_LAUNCH;
+        }
+        configured_dev[dev].store(true, std::memory_order_release);
+    }
+    // work items = images x vertical segments x 62-column strips, one workgroup per CU walking them; a segment of R
+    // rows costs R + 2 first-layer rows + LAG steps of pipeline fill + the look-ahead's fill latency
+    const int slots = srhip_num_cus();
+    const int nstrips = srhip_div_up(p.w, P::TWO);
+    int best_segs = 1;
+    double best_cost = 1e30;
+    for (int rounds = 1; rounds <= 32; ++rounds) {
+        int segs = (int)(((long long)rounds * slots) / ((long long)nstrips * p.n));
+        if (segs < 1) segs = 1;
+        if (segs > p.h) segs = p.h;
+        const int seg_h = srhip_div_up(p.h, segs);
+        segs = srhip_div_up(p.h, seg_h);
+        const long long items = (long long)segs * nstrips * p.n;
+        const int r = srhip_div_up(items, slots);
+        const double cost = (double)r * (seg_h + P::LAG + 4.0);
+        if (cost < best_cost) { best_cost = cost; best_segs = segs; }
+    }
+    p.seg_h = srhip_div_up(p.h, best_segs);
+    p.nsegs = srhip_div_up(p.h, p.seg_h);
+    p.nstrips = nstrips;
+    const long long total = (long long)p.nsegs * nstrips * p.n;
+    SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_pair: too many work items");
+    p.total_items = (int)total;
+    const int grid = (int)(total < slots ? total : slots);
+    hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
+    return srhip_check_launch("conv3x3_pair_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* a, void* stream)
+{
+    SRHIP_REQUIRE(a != nullptr, "conv3x3_pair: null args");
+    SRHIP_REQUIRE(a->src && a->wpack1 && a->wpack2 && a->dst, "conv3x3_pair: null src / wpack1 / wpack2 / dst");
+    SRHIP_REQUIRE(a->dst != a->src && a->mid != a->src && (a->mid == nullptr || a->mid != a->dst),
+                  "conv3x3_pair: src, mid and dst must be distinct tensors (neighbouring strips read src while others write dst)");
+    SRHIP_REQUIRE(a->n >= 1 && a->h >= 1 && a->w >= 1, "conv3x3_pair: empty tensor");
+    SRHIP_REQUIRE(a->act2 == SRHIP_ACT_NONE || a->act2 == SRHIP_ACT_RELU || a->act2 == SRHIP_ACT_LRELU, "conv3x3_pair: bad activation %d", a->act2);
+    SRHIP_REQUIRE(a->alpha > 0.0f, "conv3x3_pair: alpha must be positive");
+    SRHIP_REQUIRE((long long)a->h * a->w * 64 * 2 < (1ll << 31), "conv3x3_pair: image too large for 32-bit offsets");
+    PairParams p;
+    p.src = (const char*)a->src;
+    p.wpack1 = (const bf16x8*)a->wpack1;
+    p.bias1 = a->bias1;
+    p.wpack2 = (const bf16x8*)a->wpack2;
+    p.bias2 = a->bias2;
+    p.mid = (char*)a->mid;
+    p.dst = (char*)a->dst;
+    p.n = a->n; p.h = a->h; p.w = a->w;
+    p.slope2 = a->act2 == SRHIP_ACT_NONE ? 1.0f : (a->act2 == SRHIP_ACT_RELU ? 0.0f : a->slope2);
+    p.alpha = a->alpha;
+    p.cout2 = a->cout2;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->cout2 != 0 && a->cout2 != 64) {
+        SRHIP_REQUIRE(a->cout2 >= 1 && a->cout2 <= 32, "conv3x3_pair: cout2 must be 64 (or 0) or, for the head form, 1..32");
+        SRHIP_REQUIRE((long long)a->h * a->w * a->cout2 * 4 < (1ll << 31), "conv3x3_pair: head output too large for 32-bit offsets");
+        if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0, true>(p, s) : launch_pair<false, 0, true>(p, s);
+        if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1, true>(p, s) : launch_pair<false, 1, true>(p, s);
+        return a->mid != nullptr ? launch_pair<true, 2, true>(p, s) : launch_pair<false, 2, true>(p, s);
+    }
+    if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0>(p, s) : launch_pair<false, 0>(p, s);
+    if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1>(p, s) : launch_pair<false, 1>(p, s);
+    return a->mid != nullptr ? launch_pair<true, 2>(p, s) : launch_pair<false, 2>(p, s);
+}
+
+}  // extern "C"

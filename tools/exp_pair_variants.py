@@ -12,15 +12,17 @@ CSRC = os.path.join(ROOT, "superresolution_amd", "csrc")
 OUT = os.path.join(ROOT, "superresolution_amd", "_exp")
 
 L1_EPI = ("                    if constexpr (t < 8) {\n                        constexpr int qct", "                    if constexpr (false && t < 8) {\n                        constexpr int qct")
-L2_EPI = [("                constexpr bool EPI = t >= 1 && KG < P::NST;", "                constexpr bool EPI = false && t >= 1 && KG < P::NST;"),
-          ("if constexpr (ml == 0 && (t % 2 == 0) && (t / 2 < P::NST)) epi_read", "if constexpr (false && ml == 0 && (t % 2 == 0) && (t / 2 < P::NST)) epi_read"),
-          ("if constexpr (ml == 0 && (t % 2 == 1) && (t / 2 < NRES)) resv", "if constexpr (false && ml == 0 && (t % 2 == 1) && (t / 2 < NRES)) resv")]
-FRAG = [("                        bq[nxt][kr] = lds_read_b128(rowa[kyn] + rd[tn % 3][kr]);", "")]
-STAGE = [("                lds_write_acc_quad<ct, g>(wst ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);", "")]
+L2_EPI = [("                constexpr bool EPI = t >= 2;", "                constexpr bool EPI = false && t >= 2;"),
+          ("if constexpr (ml == 0 && (t % 2 == 1) && (t / 2 < P::NST)) epi_read", "if constexpr (false && ml == 0 && (t % 2 == 1) && (t / 2 < P::NST)) epi_read"),
+          ("if constexpr (ml == 0 && (t % 2 == 0) && (t / 2 < NRES)) resv", "if constexpr (false && ml == 0 && (t % 2 == 0) && (t / 2 < NRES)) resv")]
+FRAG = [("                        bq[nxt][kr] = lds_read_b128_sel<IMM, ((Q + kyn) & (P::RING - 1)) * P::SLOT_BYTES>(rowx[kyn], rd[tn % 3][kr]);", ""),
+        ("                        bq[nxt][kr] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kr]);", "")]
+STAGE = [("if constexpr (t == 0 && ml < 4) lds_write_acc_quad", "if constexpr (false && t == 0 && ml < 4) lds_write_acc_quad"),
+         ("if constexpr (t == 8 && ml >= 4) lds_write_acc_quad", "if constexpr (false && t == 8 && ml >= 4) lds_write_acc_quad")]
 DMA = [("if constexpr (t < P::MAXP && ml == 6) issue_piece(IntC<t + 0 * ml>{}, dma_soff, dma_slot);", "")]
 BARRIER = [("            __builtin_amdgcn_s_barrier();\n\n            // mid row s-1", "\n            // mid row s-1"),
-           ("            __builtin_amdgcn_s_barrier();\n            if (s >= P::LAG) row_body(IntC<0>{}, s - P::LAG);", "            if (s >= P::LAG) row_body(IntC<0>{}, s - P::LAG);"),
-           ("                __builtin_amdgcn_s_barrier();\n                if (s + 1 >= P::LAG) row_body", "                if (s + 1 >= P::LAG) row_body")]
+           ("                    __builtin_amdgcn_s_barrier();\n                    if (s + Q >= P::LAG) row_body(q_c, s + Q - P::LAG);\n                }\n            });\n        }\n        // drain",
+            "                    if (s + Q >= P::LAG) row_body(q_c, s + Q - P::LAG);\n                }\n            });\n        }\n        // drain")]
 NOPS = [('asm volatile("s_nop 15\\n\\ts_nop 3" : "+v"(acc[PAR][0]), "+v"(acc[PAR][1]));', 'asm volatile("" : "+v"(acc[PAR][0]), "+v"(acc[PAR][1]));')]
 STORES = [("            buffer_store_b128_guarded(o, dst_srd, vox[k], store_soff);", "            asm volatile(\"\" :: \"v\"(o));")]
 
