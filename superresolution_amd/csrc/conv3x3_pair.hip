@@ -488,6 +488,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
     u32x4 resv[2][NRES];
     f32x4 e_lo[2], e_hi[2];
     float ev[8];
+    u32x4 eo = {0u, 0u, 0u, 0u};   // packed results of the store group in progress
 
     for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
         const PairItem it = pair_decode_item(p, item);
@@ -519,13 +520,13 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
             if constexpr (ACT2 == 0) ev[e] = t + rv;
             else if constexpr (ACT2 == 1) ev[e] = fmaxf(t, 0.0f) + rv;
             else ev[e] = fmaxf(t, t * p.slope2) + rv;
+            // the pair's pack rides with its second element: the store step is the store alone (a step that also held
+            // the four packs overflowed the issue slots of its MFMA gap)
+            if constexpr (e & 1) eo[e >> 1] = pack_bf16x2(ev[e - 1], ev[e]);
         };
         auto epi_store = [&](auto k_c, const unsigned store_soff) {
             constexpr int k = decltype(k_c)::value;
-            u32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
-            buffer_store_b128_guarded(o, dst_srd, vox[k], store_soff);
+            buffer_store_b128_guarded(eo, dst_srd, vox[k], store_soff);
         };
 
         // One output row.  Q = o mod NY fixes the mid-ring slots of rows o .. o+2 (compile-time fragment addresses);
@@ -558,7 +559,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
             //   taps 2k+2, 2k+3 (k < 3)  channels 0..3 / 4..7 + store of group k;  tap 8: all of group 3
             static_for<0, 9>([&](auto t_c) {
                 SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
-                SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
+                SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(eo);
                 constexpr int t = decltype(t_c)::value;
                 constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
                 constexpr int tn = (t + 1) % 9;
@@ -578,7 +579,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                 constexpr int NS = ESTEPS;
                 static_for<0, P::MPT>([&](auto m_c) {
                     SRHIP_CAPTURE(resv); SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(ev);
-                    SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                    SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi); SRHIP_CAPTURE(eo);
                     constexpr int ml = decltype(m_c)::value;
                     constexpr int kc = TILE_MAJOR ? ml % P::KC : ml / P::NCT;
                     constexpr int ct = TILE_MAJOR ? ml / P::KC : ml % P::NCT;
@@ -595,7 +596,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                     if constexpr (t == 0 && ml < 4) lds_write_acc_quad<1, ml>(wst ^ (unsigned)((8 + 2 * ml) << 4), acc[1]);
                     if constexpr (t == 8 && ml >= 4) lds_write_acc_quad<0, ml - 4>(wst ^ (unsigned)((2 * (ml - 4)) << 4), acc[0]);
                     static_for<ml * NS / P::MPT, (ml + 1) * NS / P::MPT>([&](auto s_c) {
-                        SRHIP_CAPTURE(resv); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi);
+                        SRHIP_CAPTURE(resv); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(e_lo); SRHIP_CAPTURE(e_hi); SRHIP_CAPTURE(eo);
                         constexpr int S = decltype(s_c)::value;
                         if constexpr (S < ESTEPS) {
                             constexpr int KD = KG + 0 * S;
