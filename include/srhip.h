@@ -299,6 +299,15 @@ SRHIP_API int srhip_backward_warp_f32(const float* frame, const float* motion, f
 /* bf16 NHWC frame, fp32 (N,2,h,w) motion. c % 8 == 0. */
 SRHIP_API int srhip_backward_warp_nhwc(const void* frame, const float* motion, void* dst, int n,
                                        int c, int h, int w, int mode, int align_corners, void* stream);
+/* Trunk input with the previous output frame riding along (the slot core/trainer.py:130-137 fills with `velocity`
+ * and the previous `sr_frames`; warp hook core/models/model.py:142-145, warp core/tools/math.py:10-17): buffers
+ * (N,cb,h,w) and prev (N,cf,h,w) fp32 NCHW, motion (N,2,h,w) in pixels -> dst (N,h,w,16) bf16 NHWC with channels
+ * [0,cb) = buffers, [cb,cb+cf) = prev warped (zero padding), rest 0.  cb + cf <= 16.  Bit-equal to
+ * srhip_nchw_f32_to_nhwc_bf16 of the channel concatenation of buffers and srhip_backward_warp_f32(prev, motion).
+ * prev may be NULL (no previous frame: those channels are zero; motion is then unused). */
+SRHIP_API int srhip_warp_concat_nchw_f32_to_nhwc_bf16(const float* buffers, int cb, const float* prev, int cf,
+                                                      const float* motion, void* dst, int n, int h, int w, int mode,
+                                                      int align_corners, void* stream);
 /* Backward of the bilinear warp: dframe (zeroed, then scatter-add) and dmotion. */
 SRHIP_API int srhip_backward_warp_bwd_f32(const float* frame, const float* motion, const float* ddst,
                                           float* dframe, float* dmotion, int n, int c, int h, int w,

@@ -338,6 +338,21 @@ def supersampler_forward(sd, lr_frames, hr_buffers, return_intermediates=False):
     return sr
 
 
+def recurrent_forward(sd, lr_frames, hr_buffers, prev_sr=None, velocity=None):
+    """Composition the recurrent variant is held to: the previous output warped by the motion vectors
+    (core/tools/math.py:10-17 with the arguments of core/models/model_final.py:18,30: bilinear, align_corners=True)
+    concatenated behind the G-buffers, then core/models/model.py:147-175 on the wider buffer tensor.
+    hr_buffers (B,L,10,th,tw), prev_sr (B,3,th,tw) or None (zeros), velocity (B,2,th,tw)."""
+    hb = _c(hr_buffers[:, -1])
+    if prev_sr is None:
+        cf = sd["gbuffers_extractor.blks.0.0.weight"].shape[1] - hb.shape[1]
+        warped = np.zeros((hb.shape[0], cf) + hb.shape[2:], np.float32)
+    else:
+        warped = backward_warp(_c(prev_sr), _c(velocity), "bilinear", True)
+    wide = np.concatenate((hb, warped), axis=1)[:, None]
+    return supersampler_forward(sd, lr_frames, wide)
+
+
 def bf16_round(a):
     """Round an fp32 array to the nearest bf16 value (ties to even), returned as fp32."""
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

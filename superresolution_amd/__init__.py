@@ -8,6 +8,7 @@ CPU fallback: importing the operators without the built library raises.
 from . import _lib  # noqa: F401  (loads libsrhip.so, raises if it is missing)
 from . import functional  # noqa: F401
 from .model import SuperSampler  # noqa: F401
+from .recurrent import RecurrentSuperSampler  # noqa: F401
 from .reprfn import RepRFN  # noqa: F401
 
-__all__ = ["functional", "SuperSampler", "RepRFN"]
+__all__ = ["functional", "SuperSampler", "RecurrentSuperSampler", "RepRFN"]

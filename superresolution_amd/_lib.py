@@ -100,6 +100,7 @@ _SIGNATURES = {
     "srhip_l1_ssim_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_l1_ssim_loss": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 4 + [c_void_p]),
     "srhip_backward_warp_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "srhip_warp_concat_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "srhip_backward_warp_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_backward_warp_bwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "srhip_pixel_shuffle": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

@@ -966,6 +966,70 @@ __global__ void sample_f32_kernel(const float* __restrict__ src, const float* __
     }
 }
 
+// Input of the network's HR trunk when the previous output frame rides along (core/trainer.py:130-137 hands the model
+// `velocity` and the previous `sr_frames`; core/models/model.py:142-145 is the warp hook): channels [0, cb) are the
+// G-buffers, [cb, cb + cf) the previous frame warped by the motion vectors (core/tools/math.py:10-17 + grid_sample,
+// zeros padding), the rest zero; fp32 NCHW sources, ONE 16-channel NHWC bf16 pixel (32 bytes) out per thread.  Bit-equal
+// to nchw_f32_to_nhwc_bf16(cat(buffers, backward_warp_f32(prev, motion))): same operations in the same order, the fp32
+// intermediate never stored.  prev == nullptr (no previous frame yet): the warped channels are zero.
+__global__ void warp_concat_nhwc16_kernel(const float* __restrict__ buffers, const float* __restrict__ prev,
+                                          const float* __restrict__ motion, unsigned short* __restrict__ dst, int cb, int cf,
+                                          int h, int w, int mode, int align, unsigned chunks, unsigned units)
+{
+    unsigned unit;
+    if (!xcd_band_unit(units, unit)) return;   // (chunk of a row, row, image), chunk fastest, walked in XCD bands
+    const unsigned rowid = unit / chunks, chunk = unit - rowid * chunks;
+    const int x = (int)(chunk * blockDim.x + threadIdx.x);
+    if (x >= w) return;
+    const int img = (int)(rowid / (unsigned)h), y = (int)(rowid - (unsigned)img * (unsigned)h);
+    const long long hw = (long long)h * w, pix = (long long)y * w + x;
+    float v[16];
+    const float* bsrc = buffers + (long long)img * cb * hw + pix;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = k < cb ? bsrc[(long long)k * hw] : 0.0f;
+    if (prev != nullptr) {
+        const float mx = motion[((long long)img * 2 + 0) * hw + pix];
+        const float my = motion[((long long)img * 2 + 1) * hw + pix];
+        const float gx = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)x, mx), (float)(w - 1)), 2.0f), 1.0f);
+        const float gy = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn((float)y, my), (float)(h - 1)), 2.0f), 1.0f);
+        const float ix = unnorm(gx, w, align), iy = unnorm(gy, h, align);
+        const float* s = prev + (long long)img * cf * hw;
+        if (mode == SRHIP_BILINEAR) {
+            // the fp32 warp's arithmetic (sample_f32_kernel): clamped addresses, masked taps, paired loads
+            const Taps t = make_taps(ix, iy, w, h);
+            const int ya = t.vy0 ? t.y0 : (t.y0 < 0 ? 0 : h - 1), yb = t.vy1 ? t.y0 + 1 : (t.y0 + 1 < 0 ? 0 : h - 1);
+            const bool m00 = t.vy0 && t.vx0, m01 = t.vy0 && t.vx1, m10 = t.vy1 && t.vx0, m11 = t.vy1 && t.vx1;
+            const int xp = min(max(t.x0, 0), w - 2);
+            const int dx = t.x0 - xp;
+            const int oa = ya * w + xp, ob = yb * w + xp;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k >= cb && k < cb + cf) {
+                    const float* sp = s + (long long)(k - cb) * hw;
+                    const FloatPair pa = *(const FloatPair*)(sp + oa), pb = *(const FloatPair*)(sp + ob);
+                    const float a00 = dx > 0 ? pa.b : pa.a, a01 = dx < 0 ? pa.a : pa.b;
+                    const float a10 = dx > 0 ? pb.b : pb.a, a11 = dx < 0 ? pb.a : pb.b;
+                    float r = 0.0f;
+                    r = __fadd_rn(r, m00 ? __fmul_rn(a00, t.wnw) : 0.0f);
+                    r = __fadd_rn(r, m01 ? __fmul_rn(a01, t.wne) : 0.0f);
+                    r = __fadd_rn(r, m10 ? __fmul_rn(a10, t.wsw) : 0.0f);
+                    r = __fadd_rn(r, m11 ? __fmul_rn(a11, t.wse) : 0.0f);
+                    v[k] = r;
+                }
+            }
+        } else {
+            const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+            const bool ok = xn >= 0 && xn < w && yn >= 0 && yn < h;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k >= cb && k < cb + cf) v[k] = ok ? s[(long long)(k - cb) * hw + (long long)yn * w + xn] : 0.0f;
+        }
+    }
+    uint4* d = (uint4*)(dst + ((long long)img * hw + pix) * 16);
+    d[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    d[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+}
+
 // backward of the bilinear sampler: scatter-add into dsrc (fp32 atomics), optional dmotion.
 template <int GRID_FROM>
 __global__ void sample_bwd_f32_kernel(const float* __restrict__ src, const float* __restrict__ motion,
@@ -1603,6 +1667,22 @@ SRHIP_API int srhip_backward_warp_f32(const float* frame, const float* motion, f
                        (hipStream_t)stream, frame, motion, dst, n, c, h, w, h, w, mode, align_corners ? 1 : 0, CoordAxis{0, 0},
                        CoordAxis{0, 0}, (unsigned)chunks, (unsigned)units);
     return srhip_check_launch("backward_warp_f32");
+}
+
+SRHIP_API int srhip_warp_concat_nchw_f32_to_nhwc_bf16(const float* buffers, int cb, const float* prev, int cf, const float* motion,
+                                                      void* dst, int n, int h, int w, int mode, int align_corners, void* stream)
+{
+    SRHIP_REQUIRE(buffers && dst, "warp_concat: null buffers / dst");
+    SRHIP_REQUIRE(prev == nullptr || motion != nullptr, "warp_concat: a previous frame needs motion vectors");
+    SRHIP_REQUIRE(cb >= 1 && cf >= 0 && cb + cf <= 16, "warp_concat: cb + cf must fit the 16-channel pixel (got %d + %d)", cb, cf);
+    SRHIP_REQUIRE(n >= 1 && h >= 2 && w >= 2, "warp_concat: bad shape (h, w must be >= 2)");
+    SRHIP_REQUIRE(mode == SRHIP_BILINEAR || mode == SRHIP_NEAREST, "warp_concat: bad mode %d", mode);
+    SRHIP_REQUIRE(h <= 65535 && n <= 65535, "warp_concat: at most 65535 rows and images per call");
+    const long long chunks = srhip_div_up(w, kThreads), units = chunks * h * n;
+    SRHIP_REQUIRE(units < (1ll << 31), "warp_concat: too many work-groups");
+    hipLaunchKernelGGL(warp_concat_nhwc16_kernel, dim3(xcd_band_grid(units)), dim3(kThreads), 0, (hipStream_t)stream, buffers, prev,
+                       motion, (unsigned short*)dst, cb, cf, h, w, mode, align_corners ? 1 : 0, (unsigned)chunks, (unsigned)units);
+    return srhip_check_launch("warp_concat_nchw_f32_to_nhwc_bf16");
 }
 
 SRHIP_API int srhip_backward_warp_nhwc(const void* frame, const float* motion, void* dst, int n, int c, int h, int w,

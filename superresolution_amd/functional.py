@@ -651,6 +651,31 @@ def backward_warp(frame: torch.Tensor, motion: torch.Tensor, mode: str = "neares
     return out
 
 
+def warp_concat_nhwc(buffers: torch.Tensor, prev: Optional[torch.Tensor], motion: Optional[torch.Tensor],
+                     mode: str = "bilinear", align_corners: bool = True) -> torch.Tensor:
+    """(N,cb,h,w) fp32 G-buffers + the previous output (N,cf,h,w) warped by motion (N,2,h,w) -> (N,h,w,16) bf16 NHWC,
+    channels [buffers | warped previous frame | zeros], in one pass (no fp32 warp result, no fp32 concatenation).
+    prev None: the warped channels are zero."""
+    buffers = _req(buffers, torch.float32, "buffers")
+    n, cb, h, w = buffers.shape
+    cf = 0
+    if prev is not None:
+        prev = _req(prev, torch.float32, "prev")
+        if motion is None:
+            raise ValueError("warp_concat_nhwc: a previous frame needs motion vectors")
+        motion = _req(motion, torch.float32, "motion")
+        cf = prev.shape[1]
+        if tuple(prev.shape) != (n, cf, h, w) or tuple(motion.shape) != (n, 2, h, w):
+            raise ValueError("warp_concat_nhwc: prev must be (N,cf,H,W) and motion (N,2,H,W) at the buffers' size")
+    if cb + cf > 16:
+        raise ValueError(f"warp_concat_nhwc: {cb} + {cf} channels do not fit the 16-channel pixel")
+    out = torch.empty((n, h, w, 16), dtype=torch.bfloat16, device=buffers.device)
+    check(lib.srhip_warp_concat_nchw_f32_to_nhwc_bf16(buffers.data_ptr(), cb, prev.data_ptr() if prev is not None else None, cf,
+                                                      motion.data_ptr() if prev is not None else None, out.data_ptr(), n, h, w,
+                                                      _MODES[mode], int(align_corners), _stream()))
+    return out
+
+
 def backward_warp_nhwc(frame: torch.Tensor, motion: torch.Tensor, mode: str = "bilinear", align_corners: bool = True) -> torch.Tensor:
     frame = _req(frame, torch.bfloat16, "frame")
     motion = _req(motion, torch.float32, "motion")

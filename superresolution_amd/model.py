@@ -172,8 +172,10 @@ class SuperSampler(nn.Module):
 
     @torch.no_grad()
     def infer(self, lr: Tensor, hb: Tensor) -> Tensor:
-        """lr (B,3,sh,sw) fp32, hb (B,10,th,tw) fp32 -> (B,3,th,tw) fp32."""
-        th, tw = hb.shape[-2:]
+        """lr (B,3,sh,sw) fp32, hb (B,10,th,tw) fp32 -> (B,3,th,tw) fp32.  hb may also be the HR trunk's input already in
+        its device layout, (B,th,tw,16) bf16 NHWC (what ``functional.warp_concat_nhwc`` builds)."""
+        prepared = hb.dtype == torch.bfloat16
+        th, tw = hb.shape[1:3] if prepared else hb.shape[-2:]
         fc, bc, fr, bf = self.frame_channels, self.buffer_channels, self.FR_CH, self.BF_CH
 
         # frame_extractor @ LR (model.py:50-58,161)
@@ -186,7 +188,7 @@ class SuperSampler(nn.Module):
         up = F_.upsample_grid_bilinear_nhwc(f, th, tw)
 
         # gbuffers_extractor @ HR (model.py:61-79,167)
-        g = F_.nchw_f32_to_nhwc_bf16(hb.float())
+        g = hb if prepared else F_.nchw_f32_to_nhwc_bf16(hb.float())
         cin = bc
         blks = self.gbuffers_extractor.blks
         for i in range(0, len(blks), 2):

@@ -53,7 +53,8 @@ class _SuperSamplerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, lr: Tensor, hb: Tensor, *params: Tensor) -> Tensor:
         m = model
-        th, tw = hb.shape[-2:]
+        prepared = hb.dtype == torch.bfloat16   # the HR trunk's input already as (B,th,tw,16) bf16 NHWC
+        th, tw = hb.shape[1:3] if prepared else hb.shape[-2:]
         fc, bc, fr, bf, sr = m.frame_channels, m.buffer_channels, m.FR_CH, m.BF_CH, m.SR_CH
         sv = {}
         # frame extractor @ LR (core/models/model.py:50-58,161)
@@ -70,7 +71,7 @@ class _SuperSamplerFn(torch.autograd.Function):
         blks = m.gbuffers_extractor.blks
         gb = []
         bits = bf == 64 and os.environ.get("SRHIP_NO_SIGNBITS", "0") != "1"
-        prev, cin = F_.nchw_f32_to_nhwc_bf16(hb.float()), bc
+        prev, cin = (hb if prepared else F_.nchw_f32_to_nhwc_bf16(hb.float())), bc
         for i in range(0, len(blks), 2):
             if bits:
                 x, xbits = m._conv(f"ge{i}", blks[i][0], prev, cin, aux_mode=F_.AUX_EMIT)
@@ -186,6 +187,7 @@ class _SuperSamplerFn(torch.autograd.Function):
 
 def supersampler_forward_train(model, lr: Tensor, hb: Tensor) -> Tensor:
     """Differentiable forward: (B,3,sh,sw), (B,10,th,tw) fp32 -> (B,3,th,tw) fp32 with a grad_fn that
-    fills ``.grad`` of every parameter of ``model``."""
+    fills ``.grad`` of every parameter of ``model``.  hb may also be the trunk input in its device layout,
+    (B,th,tw,16) bf16 NHWC; the inputs receive no gradient either way (the reference's do not require one)."""
     params: List[Tensor] = list(model.parameters())
     return _SuperSamplerFn.apply(model, lr, hb, *params)

@@ -57,3 +57,19 @@ def test_reprfn_config_resolves_to_the_drop_in():
 def test_resolver_rejects_a_config_without_target():
     with pytest.raises(KeyError):
         instantiate_from_config({"params": {}})
+
+
+def test_recurrent_config_resolves_and_keeps_the_default_networks_tree():
+    cfg = _load("4x_H2_recurrent_amd.yaml")["params"]
+    torch.manual_seed(42)
+    model = instantiate_from_config(cfg["model_config"])
+    from superresolution_amd import RecurrentSuperSampler, SuperSampler
+    assert type(model) is RecurrentSuperSampler and isinstance(model, SuperSampler)
+    base = SuperSampler(3, 10, 1)
+    # same keys; only the first G-buffer layer is wider (10 buffer + 3 fed-back channels)
+    sd, sb = model.state_dict(), base.state_dict()
+    assert list(sd) == list(sb)
+    diff = [k for k in sd if sd[k].shape != sb[k].shape]
+    assert diff == ["gbuffers_extractor.blks.0.0.weight"] and tuple(sd[diff[0]].shape) == (64, 13, 3, 3)
+    with pytest.raises(NotImplementedError):
+        RecurrentSuperSampler(3, 10, 2)   # the reference's trainer fills the slot for n_history == 1 only
