@@ -560,7 +560,15 @@ def run_aux_infer(args, world, rank, dev, dist):
         mv = torch.randn(1, 1, 2, h, w, generator=g).to(dev)
         hf = torch.rand(1, 1, 3, h, w, generator=g).to(dev)
         hbuf = torch.rand(1, 1, 10, h, w, generator=g).to(dev)
-        step = lambda: model.infer(lr, hb.clone(), lb.clone(), mv, hf, hbuf.clone())[0]  # the depth clamp is in place
+        # the depth compression rewrites the depth channel of its three buffer inputs in place (model_final.py:462) and is
+        # not idempotent: every step starts from the original depth planes (restoring only those, not whole-tensor clones)
+        d_hb, d_lb, d_hbuf = hb[:, -1].clone(), lb[:, -1].clone(), hbuf[:, :, -1].clone()
+
+        def step():
+            hb[:, -1].copy_(d_hb)
+            lb[:, -1].copy_(d_lb)
+            hbuf[:, :, -1].copy_(d_hbuf)
+            return model.infer(lr, hb, lb, mv, hf, hbuf)[0]
         out_shape = (1, 3, 4 * h, 4 * w)
         what = ("temporal SuperSampler(3,10,4,1) (model_final.py), 544x960 -> 2176x3840 with one warped history frame, "
                 "batch 1 per GPU, clips sharded by rank")
