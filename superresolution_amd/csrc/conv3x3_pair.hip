@@ -39,6 +39,10 @@ struct PairParams {
     int n, h, w;
     float slope2, alpha;
     int nstrips, nsegs, seg_h, total_items;
+    // Two-class partition (one work item per workgroup): items [0, main_items) are the uniform (strip, segment) grid over
+    // rows [0, main_h); items [main_items, total_items) are the strips' remaining rows [main_h, h), walked with stride
+    // tail_stride by the workgroups the uniform grid leaves idle.  Uniform partition: main_items = total_items, main_h = h.
+    int main_items, main_h, tail_stride;
     int cout2;   // head form: output channels (1..32) of the second layer, written as fp32 NCHW planes
 };
 
@@ -145,15 +149,30 @@ struct PairItem {
 };
 __device__ __forceinline__ PairItem pair_decode_item(const PairParams& p, int item)
 {
-    const int strip = item % p.nstrips;
-    const int tseg = item / p.nstrips;
-    const int seg = tseg % p.nsegs;
     PairItem it;
-    it.n = tseg / p.nsegs;
-    it.x0 = strip * PairCfg::TWO;
-    it.y0 = seg * p.seg_h;
-    it.nout = min(it.y0 + p.seg_h, p.h) - it.y0;
+    if (item < p.main_items) {
+        const int strip = item % p.nstrips;
+        const int tseg = item / p.nstrips;
+        const int seg = tseg % p.nsegs;
+        it.n = tseg / p.nsegs;
+        it.x0 = strip * PairCfg::TWO;
+        it.y0 = seg * p.seg_h;
+        it.nout = min(it.y0 + p.seg_h, p.main_h) - it.y0;
+    } else {
+        const int k = item - p.main_items;
+        it.n = k / p.nstrips;
+        it.x0 = (k % p.nstrips) * PairCfg::TWO;
+        it.y0 = p.main_h;
+        it.nout = p.h - p.main_h;
+    }
     return it;
+}
+// items of this workgroup: first, first + stride, ... (a workgroup that owns a main item owns nothing else when the
+// partition has a tail class)
+__device__ __forceinline__ int pair_item_stride(const PairParams& p)
+{
+    if (p.main_items == p.total_items) return (int)gridDim.x;
+    return (int)blockIdx.x < p.main_items ? p.total_items : p.tail_stride;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -235,7 +254,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
     for (int k = 0; k < 4; ++k) midv[k] = u32x4{0u, 0u, 0u, 0u};
     unsigned e_p0 = 0, e_p1 = 0, e_addr = 0;
 
-    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+    for (int item = blockIdx.x, item_stride = pair_item_stride(p); item < p.total_items; item += item_stride) {
         const PairItem it = pair_decode_item(p, item);
         const int x0 = it.x0, y0 = it.y0, nout = it.nout;
         const int nin = nout + 4;  // x rows rx = 0..nin-1 <-> image row y0 - 2 + rx
@@ -490,7 +509,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
     float ev[8];
     u32x4 eo = {0u, 0u, 0u, 0u};   // packed results of the store group in progress
 
-    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+    for (int item = blockIdx.x, item_stride = pair_item_stride(p); item < p.total_items; item += item_stride) {
         const PairItem it = pair_decode_item(p, item);
         const int x0 = it.x0, y0 = it.y0, nout = it.nout;
         const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
@@ -703,7 +722,7 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
     bf16x8 bq[2][P::KC];
     f32x16 acc;
 
-    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+    for (int item = blockIdx.x, item_stride = pair_item_stride(p); item < p.total_items; item += item_stride) {
         const PairItem it = pair_decode_item(p, item);
         const int x0 = it.x0, y0 = it.y0, nout = it.nout;
         const unsigned plane = (unsigned)(H * W) * 4u;
@@ -808,6 +827,7 @@ int launch_pair(PairParams p, hipStream_t stream)
     // rows costs R + 2 first-layer rows + LAG steps of pipeline fill + the look-ahead's fill latency
     const int slots = srhip_num_cus();
     const int nstrips = srhip_div_up(p.w, P::TWO);
+    const double fill = P::LAG + 4.0;
     int best_segs = 1;
     double best_cost = 1e30;
     for (int rounds = 1; rounds <= 32; ++rounds) {
@@ -818,16 +838,39 @@ int launch_pair(PairParams p, hipStream_t stream)
         segs = srhip_div_up(p.h, seg_h);
         const long long items = (long long)segs * nstrips * p.n;
         const int r = srhip_div_up(items, slots);
-        const double cost = (double)r * (seg_h + P::LAG + 4.0);
+        const double cost = (double)r * (seg_h + fill);
         if (cost < best_cost) { best_cost = cost; best_segs = segs; }
     }
     p.seg_h = srhip_div_up(p.h, best_segs);
     p.nsegs = srhip_div_up(p.h, p.seg_h);
     p.nstrips = nstrips;
-    const long long total = (long long)p.nsegs * nstrips * p.n;
+    long long total = (long long)p.nsegs * nstrips * p.n;
+    p.main_items = (int)total; p.main_h = p.h; p.tail_stride = 0;
+    // Two-class partition: when a whole number of segments per strip leaves workgroups idle (4K: 62 strips x 4 = 248 of
+    // 256), the main segments shrink a little and the idle workgroups walk the rows that remain at the bottom of every
+    // strip, so that all of them finish together.
+    {
+        const long long columns = (long long)nstrips * p.n;
+        const int segs = (int)(slots / columns);
+        const int idle = (int)(slots - segs * columns);
+        if (segs >= 1 && idle >= 1 && columns < (1 << 20)) {
+            const int per_idle = srhip_div_up(columns, idle);           // tail pieces per idle workgroup
+            // main cost h1 + fill, tail cost per_idle * (L + fill) with L = h - segs * h1: balance them
+            int h1 = (int)(((double)per_idle * (p.h + fill) - fill) / (1.0 + (double)per_idle * segs)) + 1;
+            if (h1 > p.h / segs) h1 = p.h / segs;
+            const int tail_h = p.h - segs * h1;
+            const double cost = (h1 + fill > per_idle * (tail_h + fill)) ? h1 + fill : per_idle * (tail_h + fill);
+            if (h1 >= 1 && tail_h >= 1 && cost < 0.99 * best_cost) {
+                p.seg_h = h1; p.nsegs = segs; p.main_h = segs * h1;
+                p.main_items = (int)(segs * columns);
+                p.tail_stride = idle;
+                total = p.main_items + columns;
+            }
+        }
+    }
     SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_pair: too many work items");
     p.total_items = (int)total;
-    const int grid = (int)(total < slots ? total : slots);
+    const int grid = p.main_items != p.total_items ? slots : (int)(total < slots ? total : slots);
     hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
     return srhip_check_launch("conv3x3_pair_kernel");
 }
