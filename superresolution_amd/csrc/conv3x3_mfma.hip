@@ -49,6 +49,10 @@ struct ConvParams {
     char* aux;           // sign-bit tensor (N, H, ceil(W/32), 64) uint32: written (EMIT) or read (MASKBITS / DUALBITS)
     char* dst2;          // DUALBITS: second output, dst masked by the bits
     int nstrips, nsegs, seg_h, total_items;
+    // Two-class partition (one work item per workgroup): items [0, main_items) are the uniform (strip, segment) grid over
+    // rows [0, main_h); items [main_items, total_items) are the strips' remaining rows [main_h, h), walked with stride
+    // tail_stride by the workgroups the uniform grid leaves idle.  Uniform partition: main_items = total_items, main_h = h.
+    int main_items, main_h, tail_stride;
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -257,14 +261,24 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
     unsigned mbv[2] = {0u, 0u};  // sign bits of row i (loaded forms) live in mbv[i & 1]
     unsigned mb_out = 0u;        // EMIT: bits of the row whose epilogue is running
 
-    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
-        const int strip = item % p.nstrips;
-        const int tseg = item / p.nstrips;
-        const int seg = tseg % p.nsegs;
-        const int n = tseg / p.nsegs;
+    const int item_stride = p.main_items == p.total_items ? (int)gridDim.x
+                                                          : ((int)blockIdx.x < p.main_items ? p.total_items : p.tail_stride);
+    for (int item = blockIdx.x; item < p.total_items; item += item_stride) {
+        int strip, n, y0, y1;
+        if (item < p.main_items) {
+            strip = item % p.nstrips;
+            const int tseg = item / p.nstrips;
+            n = tseg / p.nsegs;
+            y0 = (tseg % p.nsegs) * p.seg_h;
+            y1 = min(y0 + p.seg_h, p.main_h);
+        } else {   // a strip's rows below the uniform grid
+            const int k = item - p.main_items;
+            strip = k % p.nstrips;
+            n = k / p.nstrips;
+            y0 = p.main_h;
+            y1 = H;
+        }
         const int x0 = strip * C::TW;
-        const int y0 = seg * p.seg_h;
-        const int y1 = min(y0 + p.seg_h, H);
         const int nout = y1 - y0;
         const int nin = nout + 2;  // input rows r = 0..nin-1  <->  y = y0 - 1 + r
 
@@ -687,10 +701,34 @@ int launch_conv(ConvParams p, hipStream_t stream)
     p.seg_h = srhip_div_up(p.h, best_segs);
     p.nsegs = srhip_div_up(p.h, p.seg_h);
     p.nstrips = nstrips;
-    const long long total = (long long)p.nsegs * nstrips * p.n;
+    long long total = (long long)p.nsegs * nstrips * p.n;
+    p.main_items = (int)total; p.main_h = p.h; p.tail_stride = 0;
+    // Two-class partition: when a whole number of segments per strip leaves workgroups idle (4K, 128-column strips:
+    // 30 x 8 = 240 of 256), the main segments shrink a little and the idle workgroups walk the rows that remain at the
+    // bottom of every strip, so that all of them finish together.
+    {
+        const double fill = 2 + 6.0;
+        const long long columns = (long long)nstrips * p.n;
+        const int segs = (int)(slots / columns);
+        const int idle = (int)(slots - segs * columns);
+        if (segs >= 1 && idle >= 1 && columns < (1 << 20)) {
+            const int per_idle = srhip_div_up(columns, idle);           // tail pieces per idle workgroup
+            // main cost h1 + fill, tail cost per_idle * (L + fill) with L = h - segs * h1: balance them
+            int h1 = (int)(((double)per_idle * (p.h + fill) - fill) / (1.0 + (double)per_idle * segs)) + 1;
+            if (h1 > p.h / segs) h1 = p.h / segs;
+            const int tail_h = p.h - segs * h1;
+            const double cost = (h1 + fill > per_idle * (tail_h + fill)) ? h1 + fill : per_idle * (tail_h + fill);
+            if (h1 >= 1 && tail_h >= 1 && cost < 0.99 * best_cost) {
+                p.seg_h = h1; p.nsegs = segs; p.main_h = segs * h1;
+                p.main_items = (int)(segs * columns);
+                p.tail_stride = idle;
+                total = p.main_items + columns;
+            }
+        }
+    }
     SRHIP_REQUIRE(total < (1ll << 30), "conv3x3: too many work items");
     p.total_items = (int)total;
-    const int grid = (int)(total < slots ? total : slots);
+    const int grid = p.main_items != p.total_items ? slots : (int)(total < slots ? total : slots);
     hipLaunchKernelGGL(conv3x3_kernel<C>, dim3(grid), dim3(C::NWAVES * 64), C::LDS_BYTES, stream, p);
     return srhip_check_launch("conv3x3_kernel");
 }

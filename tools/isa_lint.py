@@ -19,7 +19,7 @@ import sys
 import tempfile
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-S", "--cuda-device-only"]   # the product build's code generation flags (csrc/Makefile)
 LOAD_RE = re.compile(r"^(ds_read_b128|ds_read_b64_tr_b16|buffer_load_dwordx4|buffer_load_dword)\s+(v\[\d+:\d+\]|v\d+)\s*,(.*)$")
 REG_RE = re.compile(r"\bv(?:(\d+)\b|\[(\d+):(\d+)\])")
 FENCE = "; srhip-fence"
