@@ -43,6 +43,10 @@ struct PairParams {
     // rows [0, main_h); items [main_items, total_items) are the strips' remaining rows [main_h, h), walked with stride
     // tail_stride by the workgroups the uniform grid leaves idle.  Uniform partition: main_items = total_items, main_h = h.
     int main_items, main_h, tail_stride;
+    // Range partition (range_rows > 0, used when the strips outnumber the workgroups unevenly): the rows of all strips
+    // form one sequence (strip-major) and workgroup b takes rows [b * range_rows, (b + 1) * range_rows) of it, i.e. the
+    // end of one strip and the start of the next; every maximal run inside one strip is a work item.
+    int range_rows;
     int cout2;   // head form: output channels (1..32) of the second layer, written as fp32 NCHW planes
 };
 
@@ -167,12 +171,37 @@ __device__ __forceinline__ PairItem pair_decode_item(const PairParams& p, int it
     }
     return it;
 }
-// items of this workgroup: first, first + stride, ... (a workgroup that owns a main item owns nothing else when the
-// partition has a tail class)
-__device__ __forceinline__ int pair_item_stride(const PairParams& p)
+// The work items of this workgroup, in order; every wave of the workgroup walks the same sequence.
+struct PairIter {
+    int item, stride;   // item partitions: first, first + stride, ... (a workgroup that owns a main item owns nothing
+                        // else when the partition has a tail class)
+    int r, r1;          // range partition: rows [r, r1) of the strip-major row sequence
+};
+__device__ __forceinline__ PairIter pair_iter_begin(const PairParams& p)
 {
-    if (p.main_items == p.total_items) return (int)gridDim.x;
-    return (int)blockIdx.x < p.main_items ? p.total_items : p.tail_stride;
+    PairIter i;
+    i.item = (int)blockIdx.x;
+    i.stride = p.main_items == p.total_items ? (int)gridDim.x : ((int)blockIdx.x < p.main_items ? p.total_items : p.tail_stride);
+    i.r = (int)blockIdx.x * p.range_rows;
+    i.r1 = min(i.r + p.range_rows, p.nstrips * p.n * p.h);
+    return i;
+}
+__device__ __forceinline__ bool pair_iter_next(const PairParams& p, PairIter& i, PairItem& it)
+{
+    if (p.range_rows > 0) {
+        if (i.r >= i.r1) return false;
+        const int col = i.r / p.h, y = i.r - col * p.h;
+        it.n = col / p.nstrips;
+        it.x0 = (col - it.n * p.nstrips) * PairCfg::TWO;
+        it.y0 = y;
+        it.nout = min(p.h - y, i.r1 - i.r);
+        i.r += it.nout;
+        return true;
+    }
+    if (i.item >= p.total_items) return false;
+    it = pair_decode_item(p, i.item);
+    i.item += i.stride;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -254,8 +283,9 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
     for (int k = 0; k < 4; ++k) midv[k] = u32x4{0u, 0u, 0u, 0u};
     unsigned e_p0 = 0, e_p1 = 0, e_addr = 0;
 
-    for (int item = blockIdx.x, item_stride = pair_item_stride(p); item < p.total_items; item += item_stride) {
-        const PairItem it = pair_decode_item(p, item);
+    PairIter iter = pair_iter_begin(p);
+    PairItem it;
+    while (pair_iter_next(p, iter, it)) {
         const int x0 = it.x0, y0 = it.y0, nout = it.nout;
         const int nin = nout + 4;  // x rows rx = 0..nin-1 <-> image row y0 - 2 + rx
         const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
@@ -509,8 +539,9 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
     float ev[8];
     u32x4 eo = {0u, 0u, 0u, 0u};   // packed results of the store group in progress
 
-    for (int item = blockIdx.x, item_stride = pair_item_stride(p); item < p.total_items; item += item_stride) {
-        const PairItem it = pair_decode_item(p, item);
+    PairIter iter = pair_iter_begin(p);
+    PairItem it;
+    while (pair_iter_next(p, iter, it)) {
         const int x0 = it.x0, y0 = it.y0, nout = it.nout;
         const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
         const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
@@ -722,8 +753,9 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
     bf16x8 bq[2][P::KC];
     f32x16 acc;
 
-    for (int item = blockIdx.x, item_stride = pair_item_stride(p); item < p.total_items; item += item_stride) {
-        const PairItem it = pair_decode_item(p, item);
+    PairIter iter = pair_iter_begin(p);
+    PairItem it;
+    while (pair_iter_next(p, iter, it)) {
         const int x0 = it.x0, y0 = it.y0, nout = it.nout;
         const unsigned plane = (unsigned)(H * W) * 4u;
         const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -870,7 +902,22 @@ int launch_pair(PairParams p, hipStream_t stream)
     }
     SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_pair: too many work items");
     p.total_items = (int)total;
-    const int grid = p.main_items != p.total_items ? slots : (int)(total < slots ? total : slots);
+    int grid = p.main_items != p.total_items ? slots : (int)(total < slots ? total : slots);
+    // Range partition: every workgroup the same number of rows, cut wherever that falls (16 x 1024^2: 272 strips for 256
+    // workgroups, 1088 rows each = a strip and a piece of the next, against 14 rounds of 79-row items with their fills).
+    p.range_rows = 0;
+    {
+        const long long total_rows = (long long)nstrips * p.n * p.h;
+        const double now = p.main_items != p.total_items ? 0.0 : best_cost;   // a two-class partition is already balanced
+        if (now > 0.0 && total_rows >= slots && total_rows < (1ll << 30)) {
+            const int rr = (int)srhip_div_up(total_rows, slots);
+            const double cost = rr + fill * (srhip_div_up(rr, p.h) + 1);
+            if (cost < 0.97 * now) {
+                p.range_rows = rr;
+                grid = (int)srhip_div_up(total_rows, rr);
+            }
+        }
+    }
     hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
     return srhip_check_launch("conv3x3_pair_kernel");
 }
