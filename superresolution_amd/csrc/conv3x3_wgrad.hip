@@ -14,8 +14,8 @@
 //     kernel.  Rows of xin (with a one-pixel halo) and of dz stream HBM -> LDS by buffer LDS-DMA
 //     into two rings; rows and columns outside the image fail the bounds check and land as zeros,
 //     which is the zero padding and also makes partial strips contribute nothing.
-//   * Wave w owns output tile (w % NT) for all 9 taps (9 accumulators of 16 registers) plus, for
-//     ci tile 0, the bias-gradient accumulator (dz times an all-ones operand).  Layers with fewer
+//   * Wave w owns output tile (w % NT) for all 9 taps (9 accumulators of 16 registers) plus a share of
+//     the bias-gradient accumulator (dz times an all-ones operand; the waves of one co tile split the k-steps).  Layers with fewer
 //     than 4 tiles split the strip's pixels between the waves that share a tile.
 //   * Accumulators persist over every work item of the workgroup; at the end each wave writes its
 //     partial tiles to the workspace and a second kernel sums them in a fixed order
@@ -325,7 +325,9 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                     wg_mfma<ky * 3 + kx>(acc[ky * 3 + kx], join(alo[sl][sk], ahi[sl][sk]), b);
                 });
                 if constexpr (kx == 1) {
-                    if (cit == 0) wg_mfma<9>(accb, join(alo[PH][sk], ahi[PH][sk]), ones);
+                    // bias gradient: the waves that share an output-channel tile take turns over the k-steps, so that
+                    // every wave issues the same number of MFMAs per row (the reduction adds their partial sums)
+                    if (cit == sk % C::CIT) wg_mfma<9>(accb, join(alo[PH][sk], ahi[PH][sk]), ones);
                 }
                 // the LDS-DMA pieces of the rows two iterations ahead, spread over the first steps
                 wg_static_for<st * PPS, ((st + 1) * PPS < NP ? (st + 1) * PPS : NP)>([&](auto m_c) {
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         return;
     }
-    // bias gradient: the dz x ones accumulator of every (co tile, first ci tile) wave
+    // bias gradient: the dz x ones accumulators of the waves of each co tile (every ci tile holds a share)
     const int co = ((int)blockIdx.x - nvec_blocks) * 32 + o;
     int tile = 0, elem = -1;
     if (db != nullptr && co < co_real) {
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (elem >= 0) {
         for (int k = part; k < total; k += 8) {
             const int wg = k / ks, wv = tile + (k % ks) * nt;
-            sb += partial[(size_t)(wg * 4 + wv) * 10240 + elem];
+            for (int c = 0; c < cit_n; ++c) sb += partial[(size_t)(wg * 4 + wv + c) * 10240 + elem];
         }
     }
     red[part][o].x = sb;
