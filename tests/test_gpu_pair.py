@@ -150,3 +150,26 @@ def test_pair_head_rejects_bad_arguments(F_):
         F_.conv3x3_pair_head(x, wp, None, wp, None, 40)
     with pytest.raises(ValueError):
         F_.conv3x3_pair_head(x[..., :32].contiguous(), wp, None, wp, None, 3)
+
+
+@pytest.mark.parametrize("shape,kind", [((1, 1080, 1920), "two-class"), ((9, 600, 1000), "two-class"), ((16, 512, 1024), "range"),
+                                        ((2, 2160, 3840), "uniform")])
+def test_pair_work_partitions(F_, shape, kind):
+    """The launch cuts the strips into work items in three ways (uniform segments; shorter main segments plus the rows
+    left at the bottom of every strip for the workgroups a uniform grid leaves idle; equal row ranges of the strip-major
+    row sequence when the strips outnumber the workgroups unevenly).  Whatever the cut, every output row is produced
+    once, from the same inputs: given the kernel's own intermediate map the single-layer kernel reproduces the output
+    bit for bit, the intermediate map equals the single-layer first layer up to the bias-order bf16 step, and the form
+    that does not store the intermediate map gives the same output."""
+    n, h, w = shape
+    x, w1, b1, w2, b2 = _case(h + w + n, 1, 8, 8)
+    g = torch.Generator(device="cuda").manual_seed(h * 7 + n)
+    xc = (torch.rand(n, h, w, 64, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    wp1, wp2 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64), F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    out, mid = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=F_.ACT_NONE, alpha=0.2, keep_mid=True)
+    assert torch.equal(out, F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=F_.ACT_NONE, alpha=0.2)), kind
+    assert torch.equal(out, F_.conv3x3(mid, wp2, b2.cuda(), 64, res=xc, act=F_.ACT_NONE, alpha=0.2)), kind
+    t = F_.conv3x3(xc, wp1, b1.cuda(), 64, act=F_.ACT_RELU)
+    dm = (mid.float() - t.float()).abs()
+    assert float(dm.max()) <= 2.0 ** -7 * max(1.0, float(t.float().abs().max())) and float((dm > 0).float().mean()) <= 0.02, kind
+    assert bool(torch.isfinite(out.float()).all())
