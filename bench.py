@@ -157,14 +157,14 @@ def pair_roofline_block(hr_h, hr_w, avg_ms, med_ms, launches):
                          "frac": nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
-def roofline_block(kernel, flop, nbytes, avg_ms, med_ms, launches, traffic):
+def roofline_block(kernel, flop, nbytes, avg_ms, med_ms, launches, traffic, traffic_file="r1_g_conv64_pmc.csv"):
     """Roofline of the dominant kernel from its event-timed average launch duration.  Bound: HBM
     (arithmetic intensity 288 FLOP/B < 312 FLOP/B machine balance); the MFMA view is kept beside it."""
     gbs = nbytes / (avg_ms * 1e-3) / 1e9
     tflops = flop / (avg_ms * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_unit": "bytes/launch (profiles/r1_g_conv64_pmc.csv)" if traffic is not None else None,
+            "traffic_unit": f"bytes/launch (profiles/{traffic_file})" if traffic is not None else None,
             "avg_launch_ms": avg_ms, "median_launch_ms": med_ms, "launches_timed": launches,
             "algorithmic_bytes_per_launch": nbytes, "algorithmic_flop_per_launch": flop,
             "mfma_view": {"achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -394,7 +394,9 @@ def run_train(args, world, rank, dev, dist, steps=None, warmup=None, with_cpu=Tr
                    "net_frac_of_bf16_mfma_peak": flop_step / 1e12 / (ms_per_step * 1e-3) / BF16_MFMA_PEAK_TFLOPS},
         "roofline": roofline_block(f"conv3x3_kernel<Cfg<4,2,1,false,0>> (64->64 3x3 + bias + ReLU @ {B}x{S}x{S}; the same kernel "
                                    "runs every data gradient)", k_flop, 2.0 * B * S * S * 64 * 2, k_avg_ms, k_med_ms,
-                                   k_launches, None),
+                                   k_launches,
+                                   measured_traffic_bytes("r2_m_train_kernels_pmc.csv", "conv3x3_kernel<") if (B, S) == (16, 1024) else None,
+                                   "r2_m_train_kernels_pmc.csv"),
     }
     if with_cpu and not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_train(args.cpu_train_crop)

@@ -62,6 +62,13 @@ def suite(verbose=True):
                                              align_corners=True).clamp(-32, 32).contiguous()
     line("warp bilinear f32 NCHW 3ch @4K, smooth motion", timeit(lambda: F_.backward_warp(fr, smooth, "bilinear", True)),
          (2 * 3 + 2) * H * W * 4)
+    # the same warp fused with the trunk-input build of the recurrent network: 10 G-buffer planes + the warped 3-channel
+    # frame -> one 16-channel NHWC bf16 pixel (40 + 8 + 12 B read, 32 B written per pixel)
+    gb = f32(1, 10, H, W)
+    line("warp + concat + layout -> NHWC bf16 16ch @4K", timeit(lambda: F_.warp_concat_nhwc(gb, fr, mv, "bilinear", True)), (10 + 2 + 3) * H * W * 4 + 16 * H * W * 2)
+    line("warp + concat + layout -> NHWC bf16 16ch @4K, smooth motion", timeit(lambda: F_.warp_concat_nhwc(gb, fr, smooth, "bilinear", True)),
+         (10 + 2 + 3) * H * W * 4 + 16 * H * W * 2)
+    del gb
     fr16 = bf(1, H, W, 16)
     line("warp bilinear bf16 NHWC 16ch @4K", timeit(lambda: F_.backward_warp_nhwc(fr16, mv, "bilinear", True)), 2 * 16 * H * W * 2 + 2 * H * W * 4)
     line("warp bilinear bf16 NHWC 16ch @4K, smooth motion", timeit(lambda: F_.backward_warp_nhwc(fr16, smooth, "bilinear", True)),
