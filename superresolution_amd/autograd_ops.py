@@ -166,6 +166,24 @@ def resize_add(small: Tensor, addend: Tensor) -> Tensor:
     return _ResizeAdd.apply(small, addend)
 
 
+class _Resize(Function):
+    """F.interpolate(x, (ho, wo), mode="bilinear", align_corners=...) on an NHWC bf16 map; backward: the gather-form
+    adjoint kernel (no atomics: repeats bit for bit)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, ho: int, wo: int, align_corners: bool):
+        ctx.hw, ctx.align = tuple(x.shape[1:3]), align_corners
+        return F_.resize_bilinear_nhwc(x, ho, wo, align_corners=align_corners)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        return F_.resize_bilinear_bwd_nhwc(dy.contiguous(), ctx.hw[0], ctx.hw[1], align_corners=ctx.align), None, None, None
+
+
+def resize_bilinear(x: Tensor, ho: int, wo: int, align_corners: bool = False) -> Tensor:
+    return _Resize.apply(x, ho, wo, align_corners)
+
+
 class _PixelShuffleOut(Function):
     """(N,h,w,Cs) bf16 -> (N,c,h*r,w*r) fp32 (nn.PixelShuffle on the network's last feature map)."""
 
@@ -182,3 +200,104 @@ class _PixelShuffleOut(Function):
 
 def pixel_shuffle_out(x: Tensor, c: int, r: int) -> Tensor:
     return _PixelShuffleOut.apply(x, c, r)
+
+
+# ------------------------------------------------------------------------------------------------
+# Any layer functional.conv2d_auto runs (kernel 1 or 3, stride 1 or 2, any channel counts, up to three concatenated
+# sources), differentiable: the temporal network's training graph (core/models/model_final.py under loss.backward()).
+# ------------------------------------------------------------------------------------------------
+def _tile_channels(c: int) -> int:
+    """Channel count of a slice as the weight-gradient kernel tiles it (16, 32 or 64)."""
+    return 16 if c <= 16 else (32 if c <= 32 else 64)
+
+
+def _channel_slice(t: Tensor, c0: int, c1: int) -> Tensor:
+    """Channels [c0, c1) of an NHWC bf16 map as a contiguous map of 16, 32 or 64 channels (zero padded)."""
+    n = c1 - c0
+    width = _tile_channels(n)
+    if c0 == 0 and t.shape[-1] == width:
+        return t
+    out = torch.zeros(t.shape[:3] + (width,), dtype=t.dtype, device=t.device)
+    hi = min(c1, t.shape[-1])
+    out[..., :hi - c0] = t[..., c0:hi]
+    return out
+
+
+def _zero_insert2(dz: Tensor, h: int, w: int) -> Tensor:
+    """(N,ho,wo,C) -> (N,h,w,C) with dz at the even positions: a stride-2 layer's output gradient seen from the
+    stride-1 layer it is a 2x2 pick of (its data and weight gradients are that layer's on this tensor)."""
+    up = torch.zeros((dz.shape[0], h, w, dz.shape[-1]), dtype=dz.dtype, device=dz.device)
+    up[:, ::2, ::2] = dz
+    return up
+
+
+class _ConvAuto(Function):
+    """act(nn.Conv2d(concat(srcs))) through functional.conv2d_auto.  Backward, per layer shape:
+      * ReLU mask from the saved output, bias gradient = the masked gradient summed over pixels;
+      * data gradient: the same operator on transposed (3x3: and flipped) weights -- for stride 2 applied to the output
+        gradient with zeros inserted at the odd positions -- then cut into the sources' channel ranges;
+      * weight gradient: 3x3 layers on the MFMA weight-gradient kernel, one launch per (<= 64 input, <= 64 output)
+        channel slice pair, stride 2 again through the zero-inserted gradient; 1x1 layers are a plain GEMM over pixels
+        (fp32 matmul)."""
+
+    @staticmethod
+    def forward(ctx, weight: Tensor, bias: Tensor, stride: int, padding: int, act: int, *srcs: Tensor):
+        w = weight.detach().float().contiguous()
+        y = F_.conv2d_auto(tuple(srcs) if len(srcs) > 1 else srcs[0], w, bias.detach().float().contiguous(), stride=stride,
+                           padding=padding, act=act)
+        ctx.save_for_backward(w, y if act != F_.ACT_NONE else None, *srcs)
+        ctx.cfg = (stride, padding, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        w, y = ctx.saved_tensors[:2]
+        srcs = ctx.saved_tensors[2:]
+        stride, padding, act = ctx.cfg
+        cout, cin, k, _ = w.shape
+        n, h, wd = srcs[0].shape[:3]
+        dz = dy.contiguous() if y is None else F_.relu_mask(dy.contiguous(), y)
+        db = dz[..., :cout].float().sum(dim=(0, 1, 2))
+        dzs = dz if stride == 1 else _zero_insert2(dz, h, wd)         # gradient of the equivalent stride-1 layer
+        # ---- weight gradient
+        dw = torch.zeros_like(w)
+        if k == 1:
+            x2 = torch.cat([t.reshape(-1, t.shape[-1]) for t in srcs], dim=1)[:, :cin].float()
+            dw.view(cout, cin).copy_(dz.reshape(-1, dz.shape[-1])[:, :cout].float().t() @ x2)
+        else:
+            k0 = 0
+            for t in srcs:
+                for a in range(0, t.shape[-1], 64):
+                    ci = min(a + 64, t.shape[-1]) - a
+                    ci_real = min(ci, cin - (k0 + a))
+                    if ci_real <= 0:
+                        continue
+                    xs = _channel_slice(t, a, a + ci)
+                    for o in range(0, cout, 64):
+                        co = min(64, cout - o)
+                        F_.conv3x3_wgrad(xs, _channel_slice(dzs, o, o + co), dw[o:o + co], None, ci_real, co, ci_off=k0 + a)
+                k0 += t.shape[-1]
+        # ---- data gradient, cut into the sources
+        dsrcs = [None] * len(srcs)
+        if any(ctx.needs_input_grad[5:]):
+            wt = w.transpose(0, 1).flip(2, 3).contiguous() if k == 3 else w.transpose(0, 1).contiguous()
+            dx = F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2)        # (N,h,w,pad16(cin))
+            k0 = 0
+            for i, t in enumerate(srcs):
+                c = t.shape[-1]
+                if ctx.needs_input_grad[5 + i]:
+                    if k0 == 0 and dx.shape[-1] == c:
+                        dsrcs[i] = dx
+                    else:
+                        d = torch.zeros_like(t)
+                        hi = min(k0 + c, dx.shape[-1])
+                        d[..., :hi - k0] = dx[..., k0:hi]
+                        dsrcs[i] = d
+                k0 += c
+        return (dw, db, None, None, None) + tuple(dsrcs)
+
+
+def conv2d(x, weight: Tensor, bias: Tensor, stride: int = 1, padding: int = 1, act: int = F_.ACT_NONE) -> Tensor:
+    """Differentiable functional.conv2d_auto; x is an NHWC bf16 map or a tuple of maps read as their concatenation."""
+    srcs = tuple(x) if isinstance(x, (tuple, list)) else (x,)
+    return _ConvAuto.apply(weight, bias, stride, padding, act, *srcs)

@@ -5,9 +5,13 @@ hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer) -> (sr_fra
 the same module tree (hence identical ``state_dict`` keys/shapes and seed-for-seed initialisation:
 ``xavier_normal_`` on every ``nn.Conv2d``, PyTorch defaults on the transposed convolutions).
 
-Execution (inference; raises under autograd): every convolution, transposed convolution, pixel
-(un)shuffle, warp, x2 up-sampling and the gradient map run on the HIP kernels, activations NHWC
-bf16.  Every convolution goes to the MFMA kernel through ``functional.conv2d_auto`` (1x1, stride-2 and
+Execution: every convolution, transposed convolution, pixel (un)shuffle, warp, x2 up-sampling and the
+gradient map run on the HIP kernels, activations NHWC bf16.  Under autograd (training) the same forward
+is assembled from differentiable operators over the same launches (``autograd_ops.conv2d``: data
+gradient = the operator on transposed / flipped weights, stride 2 through the zero-inserted gradient;
+weight gradient = the MFMA weight-gradient kernel per <= 64-channel slice pair, a GEMM for 1x1 layers);
+the inputs receive no gradient and the history features are detached, as in the reference
+(model_final.py:489).  Every convolution goes to the MFMA kernel through ``functional.conv2d_auto`` (1x1, stride-2 and
 wide layers included; transposed 2x2 convolutions as 1x1 layers plus a depth-to-space copy).  The
 disocclusion masks with the marked history and auxiliary planes (model_final.py:53-139,472-486,501-504)
 are ONE fused kernel (``functional.disocclusion``), the depth clamp (:40-46) ``functional.clamp_depth``
@@ -19,8 +23,13 @@ from typing import Tuple
 import torch
 from torch import Tensor, nn
 
+from . import autograd_ops as A_
 from . import functional as F_
 from .tools_math import backward_warping_history
+
+
+def _add(a: Tensor, b: Tensor) -> Tensor:
+    return A_.add(a, b) if torch.is_grad_enabled() else F_.add_bf16(a, b)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -44,6 +53,9 @@ class ConvActivation(nn.Sequential):
 
     def run(self, x: Tensor, res: Tensor = None) -> Tensor:
         c = self[0]
+        if torch.is_grad_enabled():   # training graph: the same launch as a differentiable operator
+            y = A_.conv2d(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU)
+            return y if res is None else A_.add(y, res)
         return F_.conv2d_auto(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU, res=res)
 
 
@@ -53,6 +65,14 @@ class TransConvActivation(nn.Sequential):
 
     def run(self, x: Tensor) -> Tensor:
         c = self[0]
+        if torch.is_grad_enabled():
+            # stride = kernel size: a 1x1 layer to 4 * cout channels (phase-major) and a depth-to-space rearrangement; the
+            # weight rearrangement and the depth-to-space are differentiated by torch, the layer by its own operator
+            cin, cout = c.weight.shape[0], c.weight.shape[1]
+            w1 = c.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)
+            y = A_.conv2d(x, w1, c.bias.repeat(4), stride=1, padding=0, act=F_.ACT_RELU)
+            n, h, w, _ = x.shape
+            return y[..., :4 * cout].reshape(n, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, cout).contiguous()
         return F_.conv_transpose2x2s2_auto(x, c.weight, c.bias, act=F_.ACT_RELU)
 
 
@@ -61,7 +81,10 @@ def _run_seq(seq: nn.Sequential, x: Tensor) -> Tensor:
         if isinstance(m, (ConvActivation, TransConvActivation)):
             x = m.run(x)
         elif isinstance(m, nn.Upsample):  # x2 bilinear, align_corners=True (model_final.py:281-289)
-            x = F_.resize_bilinear_nhwc(x, 2 * x.shape[1], 2 * x.shape[2], align_corners=True)
+            if torch.is_grad_enabled():   # training graph: the same kernel with its adjoint as backward
+                x = A_.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], align_corners=True)
+            else:
+                x = F_.resize_bilinear_nhwc(x, 2 * x.shape[1], 2 * x.shape[2], align_corners=True)
         else:
             raise TypeError(f"unexpected module {type(m).__name__}")
     return x
@@ -109,6 +132,9 @@ class GBuffersEncoder(nn.Module):
         for m in list(self.conv_enhance)[:-1]:
             e = m.run(e)
         last = self.conv_enhance[-1][0]
+        if torch.is_grad_enabled():   # enhance_param is trained: the scale and the add stay visible to autograd
+            y = A_.conv2d(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU)
+            return fmap + self.enhance_param.to(torch.bfloat16) * y
         # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
         return F_.conv2d_auto(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU,
                               alpha=self._enhance_scale(), res=fmap)
@@ -154,10 +180,10 @@ class HistoryRefiner(nn.Module):
         x2 = self.conv2.run(self.down1.run(x1))
         x3 = self.conv3.run(self.down2.run(x2))
         u3 = _run_seq(self.up3, x3)
-        u2 = _run_seq(self.up2, F_.add_bf16(u3, x2))
-        u1 = _run_seq(self.up1, F_.add_bf16(u2, x1))
-        u0 = self.up0.run(F_.add_bf16(u1, x0))
-        return self.refine_out.run(F_.add_bf16(u0, x_in))
+        u2 = _run_seq(self.up2, _add(u3, x2))
+        u1 = _run_seq(self.up1, _add(u2, x1))
+        u0 = self.up0.run(_add(u1, x0))
+        return self.refine_out.run(_add(u0, x_in))
 
 
 class FusionNetwork(nn.Module):
@@ -223,8 +249,10 @@ class MainNetwork(nn.Module):
             F_.gradient_map(hr_buffer[i:i + 1, 6:9], self.grad_map[0].eps, out=gfull[i:i + 1, 3:6])
         grad, g_self, g_cross = self.attn_grad.run(F_.pixel_unshuffle_to_nhwc_bf16(gfull, self.sr_scale))
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
-        # model_final.py:422 (element-wise, channel-broadcast gates), one kernel
-        cur = F_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)
+        if torch.is_grad_enabled():   # model_final.py:422 as written, on the bf16 maps (gates broadcast over the channels)
+            cur = fmap_current + torch.sigmoid(f_self * g_cross) * fmap + torch.sigmoid(g_self * f_cross) * grad
+        else:                         # ... as one kernel
+            cur = F_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)
         return self.main_network.run((cur, fmap_history, fmap_gbuffer))
 
 
@@ -265,35 +293,49 @@ class SuperSampler(nn.Module):
     def forward(self, lr_frame: Tensor, hr_buffer: Tensor, lr_buffer: Tensor, motion_vectors: Tensor,
                 history_frames: Tensor, history_buffer: Tensor) -> Tuple[Tensor, Tensor]:
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the temporal SuperSampler on libsrhip is inference-only: call it under torch.no_grad()")
+            # training graph: every layer a differentiable operator over the same launches (autograd_ops.conv2d); the
+            # inputs receive no gradient, and the history features are detached as in the reference (model_final.py:489)
+            return self._forward(lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer)
         return self.infer(lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer)
 
     @torch.no_grad()
     def infer(self, lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer):
-        # depth clamp, in place like the reference (model_final.py:462-463)
-        hr_buffer[:, -1] = F_.clamp_depth(hr_buffer[:, -1])
-        lr_buffer[:, -1] = F_.clamp_depth(lr_buffer[:, -1])
-        history_buffer[:, :, -1] = F_.clamp_depth(history_buffer[:, :, -1])
-        depth_max = hr_buffer.max()      # checked at the end of the pass (below): reading it here would drain the launch queue
+        return self._forward(lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer)
+
+    def _forward(self, lr_frame, hr_buffer, lr_buffer, motion_vectors, history_frames, history_buffer):
+        training = torch.is_grad_enabled()
+        with torch.no_grad():
+            # depth clamp, in place like the reference (model_final.py:462-463)
+            hr_buffer[:, -1] = F_.clamp_depth(hr_buffer[:, -1])
+            lr_buffer[:, -1] = F_.clamp_depth(lr_buffer[:, -1])
+            history_buffer[:, :, -1] = F_.clamp_depth(history_buffer[:, :, -1])
+            depth_max = hr_buffer.max()      # checked at the end of the pass (below): reading it here would drain the launch queue
 
         fmap_bf = self.buffers_encoder.run(hr_buffer.contiguous())
         fmap_current, fmap_shadow = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(lr_frame.float().contiguous()))
 
         b, f, _, h, w = history_frames.shape
-        warped_frames, warped_buffer, motion_vectors = backward_warping_history(motion_vectors, history_frames, history_buffer)
-
-        # masks, marked history, auxiliary planes and the loss weight in one kernel (model_final.py:472-486,501-504)
-        marked_frames, aux_buffer, enhance_weight = F_.disocclusion(lr_frame.float(), lr_buffer.float(), warped_frames.float(),
-                                                                    warped_buffer.float())
-        aux_motion = motion_vectors.reshape(b * f, -1, h, w)
-
-        fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames))[0]
+        with torch.no_grad():   # functions of the inputs alone; the history features are detached (model_final.py:489)
+            warped_frames, warped_buffer, motion_vectors = backward_warping_history(motion_vectors, history_frames, history_buffer)
+            # masks, marked history, auxiliary planes and the loss weight in one kernel (model_final.py:472-486,501-504)
+            marked_frames, aux_buffer, enhance_weight = F_.disocclusion(lr_frame.float(), lr_buffer.float(), warped_frames.float(),
+                                                                        warped_buffer.float())
+            aux_motion = motion_vectors.reshape(b * f, -1, h, w)
+            fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames))[0]
         fmap_history = self.history_refiner.run(fmap_history, aux_buffer, aux_motion)          # (b*f, h, w, hs)
         if f > 1:  # (b, f*hs, h, w) in the reference: history index major, then channels
             fmap_history = fmap_history.view(b, f, h, w, -1).permute(0, 2, 3, 1, 4).reshape(b, h, w, -1).contiguous()
 
         fmap = self.main_network.run(fmap_current, fmap_history, fmap_bf, hr_buffer)
         c0, c2 = self.conv_out[0], self.conv_out[2]
+        if training:
+            t = A_.conv2d((fmap, fmap_shadow), c0.weight, c0.bias)
+            hr = A_.pixel_shuffle_out(t, self.frame_ch, self.sr_scale)                         # (b, 3, H, W) fp32
+            x16 = nn.functional.pad(hr.permute(0, 2, 3, 1), (0, 16 - self.frame_ch)).to(torch.bfloat16).contiguous()
+            y = A_.conv2d(x16, c2.weight, c2.bias, act=F_.ACT_RELU)
+            sr_frame = y[..., :self.frame_ch].permute(0, 3, 1, 2).float()
+            assert depth_max < 10, "Depth value is too large"
+            return sr_frame, enhance_weight
         t = F_.conv2d_auto((fmap, fmap_shadow), c0.weight, c0.bias)
         hr = F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale)
         wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)

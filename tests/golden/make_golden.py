@@ -556,6 +556,64 @@ def gen_temporal_model():
           "params", sum(p.numel() for p in m.parameters()))
 
 
+def gen_temporal_train():
+    """Parameter gradients of the temporal variant under the reference's own autograd: the model and weights of
+    temporal_model.npz (seed-42 initialisation rounded to bf16, its stored biases), seeded inputs at LR 48 x 64
+    (temporal_train_inputs), loss = mean((1 + enhance_weight up-sampled) * |sr - target|) + mean(sr * G) with a fixed
+    positive G, i.e. an L1 term weighted the way the variant's second output is meant to be used plus a dense
+    well-conditioned term.  6.8 M gradients are not stored: per tensor its L2 norm, eight projections on fixed +-1
+    vectors (seeded per tensor; the projections of an error estimate its norm) and, for tensors of at most 4,096
+    elements, the tensor itself."""
+    torch.cuda.current_device = lambda: "cpu"
+    import core.tools.math as mutil
+    from torch.nn import functional as F
+
+    def warp_fixed(frame, motion, mode="nearest", align_corners=True):
+        h, w = frame.shape[-2:]
+        gx = torch.arange(w).view(1, w).expand(h, -1).float()
+        gy = torch.arange(h).view(h, 1).expand(-1, w).float()
+        gx = ((gx[None, ...] + motion[:, 0]) / (w - 1)) * 2.0 - 1.0
+        gy = ((gy[None, ...] + motion[:, 1]) / (h - 1)) * 2.0 - 1.0
+        return F.grid_sample(frame, torch.stack([gx, gy], dim=-1), mode, "zeros", align_corners)
+
+    mutil.backward_warping = warp_fixed
+    import core.models.model_final as mf
+    z = np.load(os.path.join(OUT, "temporal_model.npz"))
+    torch.manual_seed(42)
+    m = mf.SuperSampler(3, 10, 4, 1)
+    with torch.no_grad():
+        for name, p in m.state_dict().items():
+            if p.dim() > 1:
+                p.copy_(bf16_round(p))
+            else:
+                p.copy_(torch.from_numpy(z["small." + name]))
+    m.train()
+    from seeded_inputs import temporal_train_inputs   # tests/golden/seeded_inputs.py: the GPU test builds the same tensors
+    args, target, G = temporal_train_inputs()
+    sr, ew = m(*[a.clone() for a in args])
+    wmap = F.interpolate(ew, size=sr.shape[-2:], mode="nearest")
+    loss = ((1.0 + wmap) * (sr - target).abs()).mean() + (sr * G).mean()
+    loss.backward()
+    out = {"loss": np.array([loss.item()], np.float32), "sr": sr.detach().numpy().astype(np.float16),
+           "enhance_weight": ew.numpy()}
+    names = []
+    for i, (name, p) in enumerate(m.named_parameters()):
+        gr = p.grad.detach().double().reshape(-1)
+        names.append(name)
+        gen = torch.Generator().manual_seed(1000 + i)
+        proj = []
+        for _ in range(8):
+            v = (torch.randint(0, 2, (gr.numel(),), generator=gen).double() * 2.0 - 1.0)
+            proj.append(float((gr * v).sum()))
+        out["norm." + name] = np.array([float(gr.norm())])
+        out["proj." + name] = np.array(proj)
+        if gr.numel() <= 4096:
+            out["grad." + name] = p.grad.detach().numpy()
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "temporal_train.npz"), **out)
+    print("temporal_train.npz: loss", loss.item(), "tensors", len(names))
+
+
 if __name__ == "__main__":
     _stub_modules()
     torch.set_num_threads(8)
@@ -580,6 +638,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_model":
         gen_temporal_model()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "temporal_train":
+        gen_temporal_train()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_ops":
         gen_temporal_ops()
         sys.exit(0)
@@ -594,3 +655,4 @@ if __name__ == "__main__":
     gen_feeder()
     gen_dilate_velocity()
     gen_temporal_model()
+    gen_temporal_train()
