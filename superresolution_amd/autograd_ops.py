@@ -233,12 +233,11 @@ def _zero_insert2(dz: Tensor, h: int, w: int) -> Tensor:
 
 class _ConvAuto(Function):
     """act(nn.Conv2d(concat(srcs))) through functional.conv2d_auto.  Backward, per layer shape:
-      * ReLU mask from the saved output, bias gradient = the masked gradient summed over pixels;
+      * ReLU mask from the saved output;
       * data gradient: the same operator on transposed (3x3: and flipped) weights -- for stride 2 applied to the output
         gradient with zeros inserted at the odd positions -- then cut into the sources' channel ranges;
-      * weight gradient: 3x3 layers on the MFMA weight-gradient kernel, one launch per (<= 64 input, <= 64 output)
-        channel slice pair, stride 2 again through the zero-inserted gradient; 1x1 layers are a plain GEMM over pixels
-        (fp32 matmul)."""
+      * weight and bias gradient: the MFMA weight-gradient kernel, one launch per (<= 64 input, <= 64 output) channel
+        slice pair, stride 2 again through the zero-inserted gradient, a 1x1 layer as the centre tap of a 3x3 one."""
 
     @staticmethod
     def forward(ctx, weight: Tensor, bias: Tensor, stride: int, padding: int, act: int, *srcs: Tensor):
@@ -257,26 +256,26 @@ class _ConvAuto(Function):
         cout, cin, k, _ = w.shape
         n, h, wd = srcs[0].shape[:3]
         dz = dy.contiguous() if y is None else F_.relu_mask(dy.contiguous(), y)
-        db = dz[..., :cout].float().sum(dim=(0, 1, 2))
         dzs = dz if stride == 1 else _zero_insert2(dz, h, wd)         # gradient of the equivalent stride-1 layer
-        # ---- weight gradient
-        dw = torch.zeros_like(w)
-        if k == 1:
-            x2 = torch.cat([t.reshape(-1, t.shape[-1]) for t in srcs], dim=1)[:, :cin].float()
-            dw.view(cout, cin).copy_(dz.reshape(-1, dz.shape[-1])[:, :cout].float().t() @ x2)
-        else:
-            k0 = 0
-            for t in srcs:
-                for a in range(0, t.shape[-1], 64):
-                    ci = min(a + 64, t.shape[-1]) - a
-                    ci_real = min(ci, cin - (k0 + a))
-                    if ci_real <= 0:
-                        continue
-                    xs = _channel_slice(t, a, a + ci)
-                    for o in range(0, cout, 64):
-                        co = min(64, cout - o)
-                        F_.conv3x3_wgrad(xs, _channel_slice(dzs, o, o + co), dw[o:o + co], None, ci_real, co, ci_off=k0 + a)
-                k0 += t.shape[-1]
+        # ---- weight and bias gradient: the MFMA weight-gradient kernel per (<= 64 input, <= 64 output) channel slice
+        # pair; a 1x1 layer is the centre tap of the 3x3 result (a GEMM over a million pixels with a 160 x 160 output
+        # is a shape the GEMM library serves three times slower than that)
+        dw3 = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
+        db = torch.zeros((cout,), dtype=torch.float32, device=w.device)
+        dz_slices = [(o, min(64, cout - o), _channel_slice(dzs, o, o + min(64, cout - o))) for o in range(0, cout, 64)]
+        k0 = 0
+        for t in srcs:
+            for a in range(0, t.shape[-1], 64):
+                ci = min(a + 64, t.shape[-1]) - a
+                ci_real = min(ci, cin - (k0 + a))
+                if ci_real <= 0:
+                    continue
+                xs = _channel_slice(t, a, a + ci)
+                for o, co, dzo in dz_slices:
+                    # the bias gradient rides on the first input slice's launch (dz times ones on the MFMA pipe)
+                    F_.conv3x3_wgrad(xs, dzo, dw3[o:o + co], db[o:o + co] if k0 + a == 0 else None, ci_real, co, ci_off=k0 + a)
+            k0 += t.shape[-1]
+        dw = dw3 if k == 3 else dw3[:, :, 1:2, 1:2].contiguous()
         # ---- data gradient, cut into the sources
         dsrcs = [None] * len(srcs)
         if any(ctx.needs_input_grad[5:]):
