@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "recurrent", "reprfn", "reprfn_train", "memops"])
+    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "temporal_train", "recurrent", "reprfn", "reprfn_train", "memops"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg of the default workload")
     ap.add_argument("--train-steps", type=int, default=8, help="timed steps of the training leg of the default workload")
@@ -465,6 +465,78 @@ def run_reprfn_train(args, world, rank, dev, dist):
                          "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None}}
 
 
+def run_temporal_train(args, world, rank, dev, dist):
+    """Training step of the temporal SuperSampler (core/models/model_final.py, n_history 1) on `train_batch` clips of one
+    history frame per GPU, LR (train_crop/4)^2: forward + enhance-weighted L1 (the variant's second output is a per-pixel
+    loss weight, model_final.py:499-505) + backward + gradient all-reduce + AdamW, data-parallel like the other two
+    networks (one flat gradient buffer, one collective)."""
+    from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters
+    from superresolution_amd.temporal import SuperSampler as TemporalSuperSampler
+    B, S = args.train_batch, args.train_crop // SCALE
+    torch.manual_seed(42)
+    model = TemporalSuperSampler(3, 10, SCALE, 1).to(dev).train()
+    broadcast_parameters(model, src=0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = FlatGradAllReducer(params, gather=True)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)
+    g = torch.Generator().manual_seed(42 + rank)
+    ins = [torch.rand(B, 3, S, S, generator=g), torch.rand(B, 10, S * SCALE, S * SCALE, generator=g), torch.rand(B, 10, S, S, generator=g),
+           torch.randn(B, 1, 2, S, S, generator=g), torch.rand(B, 1, 3, S, S, generator=g), torch.rand(B, 1, 10, S, S, generator=g)]
+    ins = [t.to(dev) for t in ins]
+    target = torch.rand(B, 3, S * SCALE, S * SCALE, generator=g).to(dev)
+    # the depth compression rewrites the depth planes of the three buffer inputs in place and is not idempotent
+    depth = [ins[1][:, -1].clone(), ins[2][:, -1].clone(), ins[5][:, :, -1].clone()]
+
+    def step():
+        ins[1][:, -1].copy_(depth[0]); ins[2][:, -1].copy_(depth[1]); ins[5][:, :, -1].copy_(depth[2])
+        red.zero_grad()
+        sr, ew = model(*ins)
+        wmap = torch.nn.functional.interpolate(ew, size=sr.shape[-2:], mode="nearest")
+        loss = ((1.0 + wmap) * (sr - target).abs()).mean()
+        loss.backward()
+        red.all_reduce()
+        opt.step()
+        return loss.detach()
+
+    with _FlopCounter() as fc, torch.no_grad():
+        model.infer(*[t.clone() for t in ins])
+    loss0 = float(step())
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    settle_host()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(loss)) and float(loss) < loss0 and bool(torch.isfinite(red.flat).all())
+    if rank != 0:
+        return None
+    ms = dt / args.steps * 1e3
+    flop_step = 3.0 * fc.flop        # forward + data gradient + weight gradient of the forward's convolution FLOPs
+    tflops = flop_step / 1e12 / (ms * 1e-3)
+    return {"metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs", "value": world * B * args.steps / dt,
+            "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"temporal SuperSampler(3,10,4,1) training, {B} clips of LR {S}x{S} (HR {S * SCALE}x{S * SCALE}) with one history "
+                                   "frame per GPU: forward + enhance-weighted L1 + backward + gradient all-reduce + AdamW, fp32 master weights",
+                       "crops_per_step_per_gpu": B, "tflop_per_step_per_gpu": flop_step / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "whole step (the forward's convolution FLOPs x 3 over the wall time of a step)",
+                         "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS,
+                         "traffic": None}}
+
+
 class _FlopCounter:
     """Algorithmic convolution FLOPs of one forward pass, counted at the operator boundary (2 * Cout * Cin * kh * kw
     per output pixel with the layer's REAL kernel size and stride; the extra work of composed launches is not
@@ -712,6 +784,14 @@ def main():
                               "roofline": {"bound": "hbm", "kernel": "sample_f32_kernel<1> (backward warp)", "achieved": warp["gbps"],
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": warp["gbps"] / HBM_PEAK_GBS, "traffic": None},
                               "ops": ops})
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "temporal_train":
+        res = run_temporal_train(args, world, rank, dev, dist)
+        if rank == 0:
+            emit(args, res)
         if dist is not None:
             dist.destroy_process_group()
         return
