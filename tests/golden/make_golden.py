@@ -556,7 +556,7 @@ def gen_temporal_model():
           "params", sum(p.numel() for p in m.parameters()))
 
 
-def gen_temporal_train():
+def gen_temporal_train(h=48, w=64, fname="temporal_train.npz"):
     """Parameter gradients of the temporal variant under the reference's own autograd: the model and weights of
     temporal_model.npz (seed-42 initialisation rounded to bf16, its stored biases), seeded inputs at LR 48 x 64
     (temporal_train_inputs), loss = mean((1 + enhance_weight up-sampled) * |sr - target|) + mean(sr * G) with a fixed
@@ -589,7 +589,7 @@ def gen_temporal_train():
                 p.copy_(torch.from_numpy(z["small." + name]))
     m.train()
     from seeded_inputs import temporal_train_inputs   # tests/golden/seeded_inputs.py: the GPU test builds the same tensors
-    args, target, G = temporal_train_inputs()
+    args, target, G = temporal_train_inputs(h, w)
     sr, ew = m(*[a.clone() for a in args])
     wmap = F.interpolate(ew, size=sr.shape[-2:], mode="nearest")
     loss = ((1.0 + wmap) * (sr - target).abs()).mean() + (sr * G).mean()
@@ -610,8 +610,10 @@ def gen_temporal_train():
         if gr.numel() <= 4096:
             out["grad." + name] = p.grad.detach().numpy()
     out["names"] = np.array(names)
-    np.savez_compressed(os.path.join(OUT, "temporal_train.npz"), **out)
-    print("temporal_train.npz: loss", loss.item(), "tensors", len(names))
+    if fname != "temporal_train.npz":   # the small-size companion only serves the error-versus-pixel-count comparison
+        out = {k: v for k, v in out.items() if k.startswith(("norm.", "proj.")) or k in ("names", "loss")}
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "loss", loss.item(), "tensors", len(names))
 
 
 if __name__ == "__main__":
@@ -640,6 +642,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_train":
         gen_temporal_train()
+        gen_temporal_train(16, 24, "temporal_train_small.npz")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "temporal_ops":
         gen_temporal_ops()
@@ -656,3 +659,4 @@ if __name__ == "__main__":
     gen_dilate_velocity()
     gen_temporal_model()
     gen_temporal_train()
+    gen_temporal_train(16, 24, "temporal_train_small.npz")
