@@ -162,10 +162,18 @@ __global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_tiled_kernel(const 
 // convolutions): out[n][y][x][c*16 + i*4 + j] = in[n][c][4y+i][4x+j].  A block takes 64 output pixels; every lane reads
 // 16 contiguous bytes (the four j of one (c, i)), pixel index fastest, and the 64 * 16c * 2 output bytes leave in linear
 // order through LDS.  LDS rows are 8-byte entries of four channels, padded by two entries.
+// WITH_MAX: block b also leaves the largest input value it read in block_max[b] (NaN if it read one, as torch.max
+// does) and block 0 fills block_max[gridDim.x .. max_cap) with -inf: the maximum of the whole tensor
+// (core/models/model_final.py:463 asserts on it) is the maximum of block_max[0 .. max_cap), with no second pass over
+// the input and no atomics.
+template <bool WITH_MAX>
 __global__ __launch_bounds__(256) void pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ src,
                                                                                     unsigned short* __restrict__ dst, int n, int c,
-                                                                                    int h, int w)
+                                                                                    int h, int w, float* __restrict__ block_max,
+                                                                                    int max_cap)
 {
+    float vmax = -INFINITY;
+    bool vnan = false;
     extern __shared__ uint4 tile[];
     uint2* t2 = (uint2*)tile;
     const int nq = c * 4, q = nq + 2, cg = c * 2;          // (c, i) pairs per pixel; row stride; 16-byte groups per pixel
@@ -185,6 +193,10 @@ __global__ __launch_bounds__(256) void pixel_unshuffle4_nchw_f32_to_nhwc_bf16_ke
                 const long long img = r / h;
                 const float4 v = *(const float4*)(src + ((img * c + (ci >> 2)) * H + 4ll * y + (ci & 3)) * W + 4ll * x);
                 t2[px * q + ci] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                if constexpr (WITH_MAX) {
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                    vnan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+                }
             }
         }
         __syncthreads();
@@ -194,6 +206,20 @@ __global__ __launch_bounds__(256) void pixel_unshuffle4_nchw_f32_to_nhwc_bf16_ke
             out[it] = *(const uint4*)(t2 + px * q + 2 * g);
         }
         __syncthreads();
+    }
+    if constexpr (WITH_MAX) {
+        float* red = (float*)tile;           // the tile is free again (barrier at the end of the loop body)
+        if (vnan) vmax = __int_as_float(0x7fc00000);
+        red[threadIdx.x] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = -INFINITY;
+            bool bad = false;
+            for (int i = 0; i < (int)blockDim.x; ++i) { const float r = red[i]; bad |= (r != r); m = fmaxf(m, r); }
+            block_max[blockIdx.x] = bad ? __int_as_float(0x7fc00000) : m;
+        }
+        if (blockIdx.x == 0)
+            for (int i = (int)gridDim.x + (int)threadIdx.x; i < max_cap; i += (int)blockDim.x) block_max[i] = -INFINITY;
     }
 }
 
@@ -858,6 +884,105 @@ __global__ void gradient_map_rows4_kernel(const float* __restrict__ src, float* 
     *(float4*)(dst + (long long)blockIdx.z * h * w + y * w + x0) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// GradientMap followed by PixelUnshuffle(4) and the NHWC bf16 conversion (core/models/model_final.py:406-409 feeds the
+// result to a convolution): out[n][y][x][k*16 + i*4 + j] = bf16(gradient of plane planes[k] of image n at (4y+i, 4x+j)).
+// The block / LDS organisation of pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel; every item computes the sixteen
+// gradients of one output pixel's 4 x 4 block of one plane from six 16-byte row loads and the two neighbours per row, in
+// the order of additions of gradient_map_rows4_kernel, so the result equals the two passes in sequence bit for bit.
+struct GradPlanes { int idx[24]; };
+__global__ __launch_bounds__(256) void gradient_map_unshuffle4_nhwc_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                               int n, int src_planes, GradPlanes planes, int c, int h,
+                                                                               int w, float eps)
+{
+    extern __shared__ uint4 tile[];
+    uint2* t2 = (uint2*)tile;
+    const int nq = c * 4, q = nq + 2, cg = c * 2;
+    const long long total = (long long)n * h * w;
+    const long long ntiles = (total + kLayoutTile - 1) / kLayoutTile;
+    const int H = 4 * h, W = 4 * w;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long p0 = t * kLayoutTile;
+        const int npx = (int)(total - p0 < kLayoutTile ? total - p0 : kLayoutTile);
+        // one item = (pixel, plane): the six input rows around the pixel's 4 x 4 block are loaded once for its four rows
+        for (int it = threadIdx.x; it < kLayoutTile * c; it += blockDim.x) {
+            const int px = it & (kLayoutTile - 1), k = it / kLayoutTile;
+            if (px < npx) {
+                const long long p = p0 + px;
+                const int x = (int)(p % w);
+                const long long r = p / w;
+                const int y = (int)(r % h);
+                const long long img = r / h;
+                const float* pl = src + (img * src_planes + planes.idx[k]) * (long long)H * W;
+                const int x0 = 4 * x;
+                float v[6][6];
+#pragma unroll
+                for (int ry = 0; ry < 6; ++ry) {
+                    const int yy = 4 * y + ry - 1;
+                    if (yy < 0 || yy >= H) {
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) v[ry][e] = 0.0f;
+                    } else {
+                        const float* row = pl + (long long)yy * W;
+                        const float4 m = *(const float4*)(row + x0);
+                        v[ry][0] = x0 > 0 ? row[x0 - 1] : 0.0f;
+                        v[ry][1] = m.x; v[ry][2] = m.y; v[ry][3] = m.z; v[ry][4] = m.w;
+                        v[ry][5] = x0 + 4 < W ? row[x0 + 4] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float gv = 0.0f, gh = 0.0f;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                gv += (float)(ky - 1) * v[i + ky][j + kx];
+                                gh += (float)(kx - 1) * v[i + ky][j + kx];
+                            }
+                        o[j] = sqrtf(gv * gv + gh * gh + eps);
+                    }
+                    t2[px * q + k * 4 + i] = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                }
+            }
+        }
+        __syncthreads();
+        uint4* out = (uint4*)(dst + p0 * (16ll * c));
+        for (int it = threadIdx.x; it < npx * cg; it += blockDim.x) {
+            const int px = it / cg, g = it - px * cg;
+            out[it] = *(const uint4*)(t2 + px * q + 2 * g);
+        }
+        __syncthreads();
+    }
+}
+
+// PixelShuffle(4) of an NHWC bf16 map written as the NHWC bf16 input of the next convolution, c <= 4 real channels in a
+// 16-channel pixel (core/models/model_final.py:446-448: conv -> PixelShuffle -> conv): out[n][4y+i][4x+j][k] =
+// in[n][y][x][k*16 + i*4 + j] for k < c, zero for k >= c.  One lane = one 16-byte half of an output pixel (the stores of a
+// wave are one contiguous kilobyte); the four lanes of an input pixel's row segment read neighbouring 2-byte elements.
+__global__ void pixel_shuffle4_nhwc_bf16_to_nhwc16_kernel(const unsigned short* __restrict__ src, uint4* __restrict__ dst, int n, int c,
+                                                          int h, int w, int cs)
+{
+    const long long total = (long long)n * h * 4 * w * 4 * 2;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if ((it & 1) == 0) {
+            const long long pix = it >> 1;
+            const int xo = (int)(pix % (4ll * w));
+            const long long r = pix / (4ll * w);     // (image, y, i) = output row
+            const unsigned short* s = src + ((r >> 2) * w + (xo >> 2)) * cs + (int)(r & 3) * 4 + (xo & 3);
+            unsigned a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = k < c ? (unsigned)s[k * 16] : 0u;
+            o.x = a[0] | (a[1] << 16);
+            o.y = a[2] | (a[3] << 16);
+        }
+        dst[it] = o;
+    }
+}
+
 // GPT = channel groups (of 8) per thread: with 2 the motion-vector and tap arithmetic (two IEEE divisions, ~150 vector
 // instructions) is paid once per 32 bytes of output instead of once per 16.
 template <int GPT>
@@ -1348,8 +1473,7 @@ __global__ void crop_flip_f16_f32_kernel(const __half* __restrict__ src, float* 
     dst[((long long)c * ch + y) * cw + x] = ((neg_mask >> c) & 1u) ? -v : v;
 }
 
-__global__ void clamp_depth_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float t1, float t2,
-                                   float log2_span)
+__global__ void clamp_depth_kernel(const float* src, float* dst, long long n, float t1, float t2, float log2_span)   // dst may be src
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float d = src[i];
@@ -1577,7 +1701,7 @@ SRHIP_API int srhip_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, in
     return srhip_check_launch("nchw_f32_to_nhwc_bf16");
 }
 
-SRHIP_API int srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, void* stream)
+static int launch_pixel_unshuffle4(const float* src, void* dst, int n, int c, int h, int w, float* block_max, int max_cap, void* stream)
 {
     SRHIP_REQUIRE(src && dst, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16: bad shape");
@@ -1585,10 +1709,29 @@ SRHIP_API int srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(const float* src, voi
     const size_t lds = (size_t)kLayoutTile * (c * 4 + 2) * sizeof(uint2);
     SRHIP_REQUIRE(lds <= 48 * 1024, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16: at most 23 input channels (got %d)", c);
     const long long ntiles = ((long long)n * h * w + kLayoutTile - 1) / kLayoutTile;
-    const long long cap = (long long)srhip_num_cus() * 16;
-    hipLaunchKernelGGL(pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds,
-                       (hipStream_t)stream, src, (unsigned short*)dst, n, c, h, w);
+    long long cap = (long long)srhip_num_cus() * 16;
+    if (block_max != nullptr) {
+        SRHIP_REQUIRE(max_cap >= 1, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16_max: max_cap must be at least 1");
+        if (cap > max_cap) cap = max_cap;
+        hipLaunchKernelGGL(pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel<true>, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256),
+                           lds, (hipStream_t)stream, src, (unsigned short*)dst, n, c, h, w, block_max, max_cap);
+    } else {
+        hipLaunchKernelGGL(pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel<false>, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256),
+                           lds, (hipStream_t)stream, src, (unsigned short*)dst, n, c, h, w, (float*)nullptr, 0);
+    }
     return srhip_check_launch("pixel_unshuffle4_nchw_f32_to_nhwc_bf16");
+}
+
+SRHIP_API int srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int n, int c, int h, int w, void* stream)
+{
+    return launch_pixel_unshuffle4(src, dst, n, c, h, w, nullptr, 0, stream);
+}
+
+SRHIP_API int srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16_max(const float* src, void* dst, int n, int c, int h, int w,
+                                                               float* block_max, int max_cap, void* stream)
+{
+    SRHIP_REQUIRE(block_max != nullptr, "pixel_unshuffle4_nchw_f32_to_nhwc_bf16_max: null block_max");
+    return launch_pixel_unshuffle4(src, dst, n, c, h, w, block_max, max_cap, stream);
 }
 
 SRHIP_API int srhip_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int n, int c, int h, int w, int cstride,
@@ -1984,6 +2127,41 @@ SRHIP_API int srhip_gradient_map_f32(const float* src, float* dst, int planes, i
         hipLaunchKernelGGL(gradient_map_kernel, dim3(grid_for((long long)planes * h * w, srhip_num_cus())), dim3(kThreads), 0,
                            (hipStream_t)stream, src, dst, (long long)planes, h, w, eps);
     return srhip_check_launch("gradient_map_f32");
+}
+
+SRHIP_API int srhip_gradient_map_unshuffle4_nhwc_bf16(const float* src, int src_planes, const int* planes, int nplanes, void* dst, int n,
+                                                      int h, int w, float eps, void* stream)
+{
+    SRHIP_REQUIRE(src && dst && planes, "gradient_map_unshuffle4_nhwc_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1 && src_planes >= 1, "gradient_map_unshuffle4_nhwc_bf16: bad shape");
+    SRHIP_REQUIRE(nplanes >= 1 && nplanes <= 23, "gradient_map_unshuffle4_nhwc_bf16: 1 to 23 planes (got %d)", nplanes);
+    SRHIP_REQUIRE((size_t)src % 16 == 0 && (size_t)dst % 16 == 0, "gradient_map_unshuffle4_nhwc_bf16: 16-byte aligned tensors");
+    SRHIP_REQUIRE((long long)h * w * 16 < (1ll << 31), "gradient_map_unshuffle4_nhwc_bf16: at most 2^31 pixels per plane");
+    GradPlanes gp;
+    for (int k = 0; k < 24; ++k) gp.idx[k] = 0;
+    for (int k = 0; k < nplanes; ++k) {
+        SRHIP_REQUIRE(planes[k] >= 0 && planes[k] < src_planes, "gradient_map_unshuffle4_nhwc_bf16: plane index %d outside the tensor", planes[k]);
+        gp.idx[k] = planes[k];
+    }
+    const size_t lds = (size_t)kLayoutTile * (nplanes * 4 + 2) * sizeof(uint2);
+    const long long ntiles = ((long long)n * h * w + kLayoutTile - 1) / kLayoutTile;
+    const long long cap = (long long)srhip_num_cus() * 16;
+    hipLaunchKernelGGL(gradient_map_unshuffle4_nhwc_bf16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds,
+                       (hipStream_t)stream, src, (unsigned short*)dst, n, src_planes, gp, nplanes, h, w, eps);
+    return srhip_check_launch("gradient_map_unshuffle4_nhwc_bf16");
+}
+
+SRHIP_API int srhip_pixel_shuffle4_nhwc_bf16_to_nhwc16(const void* src, void* dst, int n, int c, int h, int w, int cstride, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "pixel_shuffle4_nhwc_bf16_to_nhwc16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1, "pixel_shuffle4_nhwc_bf16_to_nhwc16: bad shape");
+    SRHIP_REQUIRE(c >= 1 && c <= 4 && cstride >= 16 * c && cstride % 4 == 0,
+                  "pixel_shuffle4_nhwc_bf16_to_nhwc16: 1 to 4 output channels, input pixels of at least 16 c channels");
+    SRHIP_REQUIRE((size_t)src % 8 == 0 && (size_t)dst % 16 == 0, "pixel_shuffle4_nhwc_bf16_to_nhwc16: aligned tensors");
+    const long long work = (long long)n * h * 4 * w * 4 * 2;
+    hipLaunchKernelGGL(pixel_shuffle4_nhwc_bf16_to_nhwc16_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)src, (uint4*)dst, n, c, h, w, cstride);
+    return srhip_check_launch("pixel_shuffle4_nhwc_bf16_to_nhwc16");
 }
 
 SRHIP_API int srhip_dilate_velocity_f32(const float* motion, const float* depth, float* dst, int b, int h, int w, int ksize,

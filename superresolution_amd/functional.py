@@ -6,6 +6,7 @@ own device memory and to name the current HIP stream.  NHWC tensors are plain co
 """
 from typing import Optional
 
+import ctypes
 import os
 
 import torch
@@ -417,7 +418,22 @@ def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: i
     # x may be a tuple of maps: the layer then reads their channel concatenation (torch.concat(..., dim=1) in front of a
     # convolution, core/models/model_final.py:298,375-379,424) without materialising it -- every K-slice is read from
     # the map that holds it
-    srcs = list(x) if isinstance(x, (tuple, list)) else [x]
+    # (a source may also be ``(map, first_channel, channels)``: a channel window of a wider map, read in place)
+    is_window = lambda s: isinstance(s, tuple) and len(s) == 3 and isinstance(s[1], int)
+    srcs = list(x) if isinstance(x, (tuple, list)) and not is_window(x) else [x]
+    windows = any(is_window(s) for s in srcs)
+    if windows:
+        gemm_form = use_conv_gemm and weight.shape[2] == weight.shape[3] and weight.shape[2] in (1, 3) and stride in (1, 2) \
+            and padding in (0, 1) and padding <= weight.shape[2] // 2 and alpha > 0.0 and len(srcs) <= 3 \
+            and all((s[2] if is_window(s) else s.shape[-1]) % 16 == 0 and (s[1] if is_window(s) else 0) % 8 == 0 for s in srcs)
+        if gemm_form:
+            cpad = sum(s[2] if is_window(s) else s.shape[-1] for s in srcs)
+            if cpad - cin >= 16 or cpad < cin:
+                raise ValueError("conv2d_auto: the sources' channels must add up to the layer's input channels")
+            wp = _cached_pack(weight, ("gemm", cpad), lambda: conv_gemm_pack_weights(weight.detach().float().contiguous(), cpad))
+            return conv_gemm(tuple(srcs), wp, None if bias is None else bias.detach(), cout, kh, stride=stride, padding=padding,
+                             act=act, slope=slope, alpha=alpha, res=res)
+        srcs = [s[0][..., s[1]:s[1] + s[2]].contiguous() if is_window(s) else s for s in srcs]   # every other path: copies
     if len(srcs) > 1:
         if any(t.shape[:3] != srcs[0].shape[:3] for t in srcs) or sum(t.shape[-1] for t in srcs) - cin >= 16:
             raise ValueError("conv2d_auto: concatenated sources must share (N,H,W) and carry no channel padding except the last")
@@ -732,16 +748,51 @@ def pixel_unshuffle(x: torch.Tensor, r: int) -> torch.Tensor:
     return out
 
 
-def pixel_unshuffle_to_nhwc_bf16(x: torch.Tensor, r: int) -> torch.Tensor:
-    """nchw_f32_to_nhwc_bf16(pixel_unshuffle(x, r)) -- one kernel for r = 4 and up to 23 channels, the pair otherwise."""
+def pixel_unshuffle_to_nhwc_bf16(x: torch.Tensor, r: int, want_max: bool = False):
+    """nchw_f32_to_nhwc_bf16(pixel_unshuffle(x, r)) -- one kernel for r = 4 and up to 23 channels, the pair otherwise.
+    want_max: also return x.max() as a 0-d device tensor (NaN if x holds one), found by the same pass over x."""
     x = _req(x, torch.float32, "x")
     n, c, hr, wr = x.shape
     if hr % r or wr % r:
         raise ValueError("pixel_unshuffle: spatial size not divisible by r")
     if r != 4 or c > 23:
-        return nchw_f32_to_nhwc_bf16(pixel_unshuffle(x, r))
+        out = nchw_f32_to_nhwc_bf16(pixel_unshuffle(x, r))
+        return (out, x.max()) if want_max else out
     out = torch.empty((n, hr // 4, wr // 4, 16 * c), dtype=torch.bfloat16, device=x.device)
+    if want_max:
+        part = torch.empty(4096, dtype=torch.float32, device=x.device)
+        check(lib.srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16_max(x.data_ptr(), out.data_ptr(), n, c, hr // 4, wr // 4,
+                                                                   part.data_ptr(), part.numel(), _stream()))
+        return out, part.max()
     check(lib.srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(x.data_ptr(), out.data_ptr(), n, c, hr // 4, wr // 4, _stream()))
+    return out
+
+
+def gradient_map_unshuffle_nhwc(x: torch.Tensor, planes, eps: float = 1e-6) -> torch.Tensor:
+    """nchw_f32_to_nhwc_bf16(pixel_unshuffle(gradient_map(x[:, planes]), 4)) in one pass (GradientMap + PixelUnshuffle of
+    core/models/model_final.py:406-409): x (N,C,4h,4w) fp32 -> (N,h,w,16*len(planes)) bf16."""
+    x = _req(x, torch.float32, "x")
+    n, cs, hr, wr = x.shape
+    planes = [int(k) for k in planes]
+    if hr % 4 or wr % 4:
+        raise ValueError("gradient_map_unshuffle_nhwc: spatial size not divisible by 4")
+    if not 1 <= len(planes) <= 23 or any(k < 0 or k >= cs for k in planes):
+        raise ValueError("gradient_map_unshuffle_nhwc: 1 to 23 plane indices inside the tensor")
+    out = torch.empty((n, hr // 4, wr // 4, 16 * len(planes)), dtype=torch.bfloat16, device=x.device)
+    idx = (ctypes.c_int * len(planes))(*planes)
+    check(lib.srhip_gradient_map_unshuffle4_nhwc_bf16(x.data_ptr(), cs, idx, len(planes), out.data_ptr(), n, hr // 4, wr // 4, eps, _stream()))
+    return out
+
+
+def pixel_shuffle4_nhwc_to_nhwc16(x: torch.Tensor, c: int) -> torch.Tensor:
+    """PixelShuffle(4) of an NHWC bf16 map with at least 16c channels, written as the 16-channel NHWC bf16 input of the next
+    convolution (channels >= c zero): (N,h,w,cs) -> (N,4h,4w,16).  c <= 4."""
+    x = _req(x, torch.bfloat16, "x")
+    n, h, w, cs = x.shape
+    if not 1 <= c <= 4 or cs < 16 * c:
+        raise ValueError("pixel_shuffle4_nhwc_to_nhwc16: 1 to 4 output channels out of at least 16 c input channels")
+    out = torch.empty((n, 4 * h, 4 * w, 16), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_pixel_shuffle4_nhwc_bf16_to_nhwc16(x.data_ptr(), out.data_ptr(), n, c, h, w, cs, _stream()))
     return out
 
 
@@ -836,9 +887,11 @@ def layernorm_cf_autograd(x: torch.Tensor, weight: torch.Tensor, bias: torch.Ten
 # temporal variant: disocclusion logic, depth compression
 # ------------------------------------------------------------------------------------------------
 def disocclusion(cur_frame: torch.Tensor, cur_buffer: torch.Tensor, hist_frames: torch.Tensor, hist_buffer: torch.Tensor,
-                 want_mask: bool = False):
+                 want_mask: bool = False, aux_planes: int = 14):
     """core/models/model_final.py:472-486,501-504 in one kernel -> (marked_frames (B*F,3,h,w), aux (B*F,14,h,w),
-    enhance_weight (B,1,h,w)[, mask (B,F,1,h,w) bool])."""
+    enhance_weight (B,1,h,w)[, mask (B,F,1,h,w) bool]).  aux_planes > 14 (only for B*F == 1, where the 14 planes are a
+    contiguous prefix) returns aux as (1,aux_planes,h,w) with the planes behind the fourteenth left for the caller to
+    fill: the history refiner's input is these planes followed by |motion| (model_final.py:300)."""
     cur_frame = _req(cur_frame, torch.float32, "cur_frame")
     cur_buffer = _req(cur_buffer, torch.float32, "cur_buffer")
     hist_frames = _req(hist_frames, torch.float32, "hist_frames")
@@ -850,7 +903,9 @@ def disocclusion(cur_frame: torch.Tensor, cur_buffer: torch.Tensor, hist_frames:
                          "hist_buffer (B,F,10,h,w)")
     dev = cur_frame.device
     marked = torch.empty((b * f, 3, h, w), dtype=torch.float32, device=dev)
-    aux = torch.empty((b * f, 14, h, w), dtype=torch.float32, device=dev)
+    if aux_planes != 14 and (aux_planes < 14 or b * f != 1):
+        raise ValueError("disocclusion: aux_planes > 14 needs B*F == 1")
+    aux = torch.empty((b * f, aux_planes, h, w), dtype=torch.float32, device=dev)
     ew = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
     mask = torch.empty((b, f, 1, h, w), dtype=torch.uint8, device=dev) if want_mask else None
     check(lib.srhip_disocclusion_f32(cur_frame.data_ptr(), cur_buffer.data_ptr(), hist_frames.data_ptr(), hist_buffer.data_ptr(),
@@ -861,7 +916,10 @@ def disocclusion(cur_frame: torch.Tensor, cur_buffer: torch.Tensor, hist_frames:
 def clamp_depth(depth: torch.Tensor, thres1: float = 3.0, thres2: float = 7.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """core/models/model_final.py:40-46 (identity below thres1, so no host-side max() test)."""
     depth = _req(depth, torch.float32, "depth")
-    out = torch.empty_like(depth) if out is None else out
+    if out is None:
+        out = torch.empty_like(depth)
+    elif out.dtype != torch.float32 or out.shape != depth.shape or not out.is_contiguous() or out.device != depth.device:
+        raise ValueError("clamp_depth: out must be a contiguous fp32 tensor of depth's shape on depth's device (it may be depth itself)")
     check(lib.srhip_clamp_depth_f32(depth.data_ptr(), out.data_ptr(), depth.numel(), thres1, thres2, _stream()))
     return out
 

@@ -76,18 +76,24 @@ class TransConvActivation(nn.Sequential):
         return F_.conv_transpose2x2s2_auto(x, c.weight, c.bias, act=F_.ACT_RELU)
 
 
-def _run_seq(seq: nn.Sequential, x: Tensor) -> Tensor:
-    for m in seq:
+def _run_seq(seq: nn.Sequential, x: Tensor, addend: Tensor = None) -> Tensor:
+    """The layers of `seq` in order; `addend` (a skip connection, model_final.py:308-313) is added to the result: by the
+    up-sampling pass itself where the sequence ends in one and no graph is recorded, by an add otherwise."""
+    last = len(seq) - 1
+    for i, m in enumerate(seq):
         if isinstance(m, (ConvActivation, TransConvActivation)):
             x = m.run(x)
         elif isinstance(m, nn.Upsample):  # x2 bilinear, align_corners=True (model_final.py:281-289)
             if torch.is_grad_enabled():   # training graph: the same kernel with its adjoint as backward
                 x = A_.resize_bilinear(x, 2 * x.shape[1], 2 * x.shape[2], align_corners=True)
             else:
-                x = F_.resize_bilinear_nhwc(x, 2 * x.shape[1], 2 * x.shape[2], align_corners=True)
+                fused = addend if i == last else None
+                x = F_.resize_bilinear_nhwc(x, 2 * x.shape[1], 2 * x.shape[2], addend=fused, align_corners=True)
+                if fused is not None:
+                    addend = None
         else:
             raise TypeError(f"unexpected module {type(m).__name__}")
-    return x
+    return x if addend is None else _add(x, addend)
 
 
 class FrameEncoder(nn.Module):
@@ -116,15 +122,25 @@ class GBuffersEncoder(nn.Module):
                                           ConvActivation(cout, cout, 1, padding=0), ConvActivation(cout, cout, 1, padding=0))
         self.enhance_param = nn.Parameter(torch.tensor(0.45), requires_grad=True)
 
-    def run(self, buffer: Tensor) -> Tensor:
-        """buffer (B,10,H,W) fp32 -> (B,h,w,cout) bf16 (model_final.py:250-258)."""
+    def run(self, buffer: Tensor, want_max: bool = False):
+        """buffer (B,10,H,W) fp32 -> (B,h,w,cout) bf16 (model_final.py:250-258); want_max: also buffer.max() (0-d device
+        tensor), found by the pass that folds the buffer."""
+        out = self._run(buffer, want_max)
+        return out if want_max else out[0]
+
+    def _run(self, buffer: Tensor, want_max: bool):
         r2 = self.factor ** 2
         # folded buffer, channel c*r2 + i*r + j, straight in the convolutions' layout; below: normal (0:3), base colour
         # (6:9) and depth (9:10) planes of it
-        fn = F_.pixel_unshuffle_to_nhwc_bf16(buffer, self.factor)
+        if want_max:
+            fn, vmax = F_.pixel_unshuffle_to_nhwc_bf16(buffer, self.factor, want_max=True)
+        else:
+            fn, vmax = F_.pixel_unshuffle_to_nhwc_bf16(buffer, self.factor), None
         fmap = _run_seq(self.conv_main, fn)
         # picked from the converted map (the conversion rounds element by element, so the order does not matter)
-        if r2 % 2 == 0 and fn.shape[-1] % 2 == 0:      # copy channel pairs as 32-bit words
+        if not torch.is_grad_enabled() and r2 % 16 == 0:
+            e = ((fn, 0, 3 * r2), (fn, 6 * r2, 4 * r2))   # the first enhance layer reads the two channel windows in place
+        elif r2 % 2 == 0 and fn.shape[-1] % 2 == 0:      # copy channel pairs as 32-bit words
             f32 = fn.view(torch.int32)
             e = torch.cat((f32[..., 0:3 * r2 // 2], f32[..., 3 * r2:5 * r2]), dim=-1).view(torch.bfloat16)
         else:
@@ -134,10 +150,10 @@ class GBuffersEncoder(nn.Module):
         last = self.conv_enhance[-1][0]
         if torch.is_grad_enabled():   # enhance_param is trained: the scale and the add stay visible to autograd
             y = A_.conv2d(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU)
-            return fmap + self.enhance_param.to(torch.bfloat16) * y
+            return fmap + self.enhance_param.to(torch.bfloat16) * y, vmax
         # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
         return F_.conv2d_auto(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU,
-                              alpha=self._enhance_scale(), res=fmap)
+                              alpha=self._enhance_scale(), res=fmap), vmax
 
     def _enhance_scale(self) -> float:
         """enhance_param as a host number, read from the device only when the parameter changed (reading it per
@@ -172,18 +188,22 @@ class HistoryRefiner(nn.Module):
         self.refine_out = ConvActivation(up_chs[0], cout, 1, padding=0)
 
     def run(self, x: Tensor, aux: Tensor, motion: Tensor) -> Tensor:
-        """x (N,h,w,64) bf16; aux (N,14,h,w), motion (N,2,h,w) fp32 (model_final.py:295-315)."""
+        """x (N,h,w,64) bf16; aux (N,14,h,w), motion (N,2,h,w) fp32 (model_final.py:295-315).  aux may come with two spare
+        planes behind its fourteen ((1,16,h,w), ``functional.disocclusion(aux_planes=16)``): |motion| is written there."""
         x_in = self.refine_in.run(x)
-        extra = F_.nchw_f32_to_nhwc_bf16(torch.cat((aux, motion.abs()), dim=1).contiguous())   # 16 channels
+        if aux.shape[1] == 16:
+            torch.abs(motion, out=aux[:, 14:16])
+            extra = F_.nchw_f32_to_nhwc_bf16(aux)
+        else:
+            extra = F_.nchw_f32_to_nhwc_bf16(torch.cat((aux, motion.abs()), dim=1).contiguous())   # 16 channels
         x0 = self.conv0.run((x_in, extra))                # the layer reads the concatenation in place
         x1 = self.conv1.run(self.down0.run(x0))
         x2 = self.conv2.run(self.down1.run(x1))
         x3 = self.conv3.run(self.down2.run(x2))
-        u3 = _run_seq(self.up3, x3)
-        u2 = _run_seq(self.up2, _add(u3, x2))
-        u1 = _run_seq(self.up1, _add(u2, x1))
-        u0 = self.up0.run(_add(u1, x0))
-        return self.refine_out.run(_add(u0, x_in))
+        s2 = _run_seq(self.up3, x3, addend=x2)            # up3(x3) + x2, ...
+        s1 = _run_seq(self.up2, s2, addend=x1)
+        s0 = _run_seq(self.up1, s1, addend=x0)
+        return self.refine_out.run(self.up0.run(s0, res=x_in))
 
 
 class FusionNetwork(nn.Module):
@@ -242,12 +262,16 @@ class MainNetwork(nn.Module):
 
     def run(self, fmap_current: Tensor, fmap_history: Tensor, fmap_gbuffer: Tensor, hr_buffer: Tensor) -> Tensor:
         # normal and base-colour planes (model_final.py:417); each range is contiguous per sample, so no copy is made
-        nb, _, hh, ww = hr_buffer.shape
-        gfull = torch.empty((nb, 6, hh, ww), dtype=torch.float32, device=hr_buffer.device)
-        for i in range(nb):
-            F_.gradient_map(hr_buffer[i:i + 1, 0:3], self.grad_map[0].eps, out=gfull[i:i + 1, 0:3])
-            F_.gradient_map(hr_buffer[i:i + 1, 6:9], self.grad_map[0].eps, out=gfull[i:i + 1, 3:6])
-        grad, g_self, g_cross = self.attn_grad.run(F_.pixel_unshuffle_to_nhwc_bf16(gfull, self.sr_scale))
+        if self.sr_scale == 4:   # gradient map, PixelUnshuffle and the layout conversion in one pass over the six planes
+            folded = F_.gradient_map_unshuffle_nhwc(hr_buffer, (0, 1, 2, 6, 7, 8), self.grad_map[0].eps)
+        else:
+            nb, _, hh, ww = hr_buffer.shape
+            gfull = torch.empty((nb, 6, hh, ww), dtype=torch.float32, device=hr_buffer.device)
+            for i in range(nb):
+                F_.gradient_map(hr_buffer[i:i + 1, 0:3], self.grad_map[0].eps, out=gfull[i:i + 1, 0:3])
+                F_.gradient_map(hr_buffer[i:i + 1, 6:9], self.grad_map[0].eps, out=gfull[i:i + 1, 3:6])
+            folded = F_.pixel_unshuffle_to_nhwc_bf16(gfull, self.sr_scale)
+        grad, g_self, g_cross = self.attn_grad.run(folded)
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
         if torch.is_grad_enabled():   # model_final.py:422 as written, on the bf16 maps (gates broadcast over the channels)
             cur = fmap_current + torch.sigmoid(f_self * g_cross) * fmap + torch.sigmoid(g_self * f_cross) * grad
@@ -306,12 +330,15 @@ class SuperSampler(nn.Module):
         training = torch.is_grad_enabled()
         with torch.no_grad():
             # depth clamp, in place like the reference (model_final.py:462-463)
-            hr_buffer[:, -1] = F_.clamp_depth(hr_buffer[:, -1])
-            lr_buffer[:, -1] = F_.clamp_depth(lr_buffer[:, -1])
-            history_buffer[:, :, -1] = F_.clamp_depth(history_buffer[:, :, -1])
-            depth_max = hr_buffer.max()      # checked at the end of the pass (below): reading it here would drain the launch queue
+            for planes in (hr_buffer[:, -1], lr_buffer[:, -1], history_buffer[:, :, -1]):
+                if planes.is_contiguous() and planes.dtype == torch.float32:      # one sample: the planes are one range
+                    F_.clamp_depth(planes, out=planes)
+                else:
+                    planes.copy_(F_.clamp_depth(planes))
 
-        fmap_bf = self.buffers_encoder.run(hr_buffer.contiguous())
+        # the maximum of the clamped buffer (model_final.py:463) comes out of the pass that folds it; it is checked at
+        # the end of the pass (below): reading it here would drain the launch queue
+        fmap_bf, depth_max = self.buffers_encoder.run(hr_buffer.contiguous(), want_max=True)
         fmap_current, fmap_shadow = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(lr_frame.float().contiguous()))
 
         b, f, _, h, w = history_frames.shape
@@ -319,7 +346,7 @@ class SuperSampler(nn.Module):
             warped_frames, warped_buffer, motion_vectors = backward_warping_history(motion_vectors, history_frames, history_buffer)
             # masks, marked history, auxiliary planes and the loss weight in one kernel (model_final.py:472-486,501-504)
             marked_frames, aux_buffer, enhance_weight = F_.disocclusion(lr_frame.float(), lr_buffer.float(), warped_frames.float(),
-                                                                        warped_buffer.float())
+                                                                        warped_buffer.float(), aux_planes=16 if b * f == 1 else 14)
             aux_motion = motion_vectors.reshape(b * f, -1, h, w)
             fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames))[0]
         fmap_history = self.history_refiner.run(fmap_history, aux_buffer, aux_motion)          # (b*f, h, w, hs)
@@ -337,9 +364,12 @@ class SuperSampler(nn.Module):
             assert depth_max < 10, "Depth value is too large"
             return sr_frame, enhance_weight
         t = F_.conv2d_auto((fmap, fmap_shadow), c0.weight, c0.bias)
-        hr = F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale)
+        if self.sr_scale == 4 and self.frame_ch <= 4:   # PixelShuffle straight into the last layer's padded input layout
+            hr16 = F_.pixel_shuffle4_nhwc_to_nhwc16(t, self.frame_ch)
+        else:
+            hr16 = F_.nchw_f32_to_nhwc_bf16(F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale))
         wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)
-        sr_frame = F_.conv3x3(F_.nchw_f32_to_nhwc_bf16(hr), wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)
+        sr_frame = F_.conv3x3(hr16, wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)
 
         # model_final.py:464; the comparison waits for the device, so it runs once every launch of the pass is queued
         assert depth_max < 10, "Depth value is too large"

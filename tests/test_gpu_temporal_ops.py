@@ -199,3 +199,85 @@ def test_fused_pixel_unshuffle_layout_bit_exact(F_, shape):
     assert got.shape == ref.shape and got.dtype == torch.bfloat16 and torch.equal(got, ref)
     x2 = dev(rng.standard_normal((1, 3, 6, 10)).astype(np.float32))
     assert torch.equal(F_.pixel_unshuffle_to_nhwc_bf16(x2, 2), F_.nchw_f32_to_nhwc_bf16(F_.pixel_unshuffle(x2, 2)))
+
+
+@pytest.mark.parametrize("shape", [(1, 10, 16, 24), (2, 6, 20, 52), (1, 10, 544, 960), (1, 3, 6, 10)])
+def test_fused_pixel_unshuffle_also_yields_the_maximum(F_, shape):
+    """The maximum the temporal network asserts on (core/models/model_final.py:463) out of the folding pass: equal to
+    torch.max bit for bit (negative-only tensors, a maximum in the last partial tile, more tiles than work-groups), NaN
+    when the tensor holds one, and the folded map is the one the plain entry point writes."""
+    rng = np.random.default_rng(sum(shape))
+    r = 4 if shape[2] % 4 == 0 and shape[3] % 4 == 0 else 2
+    for variant in ("normal", "negative", "last", "nan"):
+        a = rng.standard_normal(shape).astype(np.float32)
+        if variant == "negative":
+            a = -np.abs(a) - 0.25
+        if variant == "last":
+            a[-1, -1, -1, -1] = 77.5
+        if variant == "nan":
+            a[0, 0, shape[2] // 2, 1] = np.nan
+        x = dev(a)
+        got, vmax = F_.pixel_unshuffle_to_nhwc_bf16(x, r, want_max=True)
+        assert vmax.dim() == 0 and vmax.dtype == torch.float32
+        if variant == "nan":
+            assert bool(torch.isnan(vmax)) and not bool(vmax < 10)      # the reference's assert fires on NaN as well
+            continue
+        assert float(vmax) == float(x.max())
+        assert torch.equal(got, F_.pixel_unshuffle_to_nhwc_bf16(x, r))
+
+
+def test_disocclusion_with_spare_auxiliary_planes_and_in_place_depth_clamp(F_):
+    """aux_planes=16 leaves two planes behind the fourteen for |motion| (the history refiner's input,
+    model_final.py:300) without a concatenation; clamp_depth may write over its input."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "temporal_masks.npz"))
+    done = 0
+    for t in "abc":
+        args = [torch.from_numpy(z[f"{t}.{k}"]).cuda() for k in ("lr_frame", "lr_buffer", "warped_frames", "warped_buffer")]
+        if args[2].shape[0] * args[2].shape[1] != 1:
+            with pytest.raises(ValueError):
+                F_.disocclusion(*args, aux_planes=16)
+            continue
+        marked, aux, ew = F_.disocclusion(*args, aux_planes=16)
+        assert tuple(aux.shape[:2]) == (1, 16) and np.array_equal(aux[:, :14].cpu().numpy(), z[t + ".aux"])
+        assert np.array_equal(marked.cpu().numpy(), z[t + ".marked_frames"]) and np.array_equal(ew.cpu().numpy(), z[t + ".enhance_weight"])
+        done += 1
+    g = torch.Generator().manual_seed(3)
+    cf, cb = torch.rand(1, 3, 9, 13, generator=g).cuda(), torch.rand(1, 10, 9, 13, generator=g).cuda()
+    hf, hb = torch.rand(1, 1, 3, 9, 13, generator=g).cuda(), torch.rand(1, 1, 10, 9, 13, generator=g).cuda()
+    _, aux14, _ = F_.disocclusion(cf, cb, hf, hb)
+    _, aux16, _ = F_.disocclusion(cf, cb, hf, hb, aux_planes=16)
+    assert torch.equal(aux16[:, :14], aux14)
+    d = (torch.rand(2, 33, 17, generator=g) * 12).cuda()
+    want = F_.clamp_depth(d)
+    assert F_.clamp_depth(d, out=d) is d and torch.equal(d, want)
+    with pytest.raises(ValueError):
+        F_.clamp_depth(want, out=want[:, ::2])
+
+
+@pytest.mark.parametrize("shape", [(1, 10, 16, 24), (2, 10, 20, 52), (1, 10, 544, 960), (3, 4, 4, 4)])
+def test_fused_gradient_map_unshuffle_bit_exact(F_, shape):
+    """GradientMap + PixelUnshuffle(4) + NHWC bf16 conversion in one pass == the three kernels in sequence, bit for bit
+    (image borders, 64-pixel tiles that straddle rows and images, planes taken out of order)."""
+    rng = np.random.default_rng(sum(shape))
+    x = dev(rng.standard_normal(shape).astype(np.float32))
+    for planes in ((0, 1, 2, 6, 7, 8), (3,), (2, 0)):
+        planes = tuple(k % shape[1] for k in planes)
+        got = F_.gradient_map_unshuffle_nhwc(x, planes, 1e-6)
+        ref = F_.pixel_unshuffle_to_nhwc_bf16(F_.gradient_map(x[:, list(planes)].contiguous(), 1e-6), 4)
+        assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    with pytest.raises(ValueError):
+        F_.gradient_map_unshuffle_nhwc(x, (shape[1],))
+
+
+@pytest.mark.parametrize("shape,c", [((1, 5, 7, 48), 3), ((2, 9, 4, 64), 4), ((1, 136, 240, 48), 3), ((1, 3, 3, 16), 1)])
+def test_pixel_shuffle_into_the_padded_nhwc_layout_is_a_permutation(F_, shape, c):
+    """PixelShuffle(4) between two convolutions without the fp32 NCHW detour: equal bit for bit to the fused NHWC -> NCHW
+    fp32 head followed by the layout conversion (both exact on bf16 values), padding channels zero."""
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(*shape, generator=g).to(torch.bfloat16).cuda()
+    got = F_.pixel_shuffle4_nhwc_to_nhwc16(x, c)
+    ref = F_.nchw_f32_to_nhwc_bf16(F_.pixel_shuffle_nhwc_to_nchw_f32(x, c, 4), 16)
+    assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    assert not got[..., c:].any()
+    with pytest.raises(ValueError):
+        F_.pixel_shuffle4_nhwc_to_nhwc16(x, 5)
