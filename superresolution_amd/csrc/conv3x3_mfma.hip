@@ -166,6 +166,11 @@ struct Cfg {
     // PREVIOUS tap (gap 0: staging read-back, gaps 1..KC: pixel fragments), and a tap starts with a plain
     // wait for everything issued at least MPT - KC - 1 MFMAs ago.
     static constexpr bool SPREAD = MPT >= KC + 2;
+    // One MFMA per fragment (one cout tile per wave) and a wide K: the fragments of the next tap still go between the
+    // MFMAs, two behind the first and one behind each of the next KC - 2, so that the last MFMA of the tap covers the
+    // last read.  (Issued as one burst in front of the tap, the six reads of the four waves queue up at the LDS while
+    // the matrix pipe runs dry: 18 % of the 32 + 64 -> 64 layer's time.)
+    static constexpr bool TIGHT = !SPREAD && MPT == KC && KC >= 4;
     // micro-steps run between the MFMAs of tap t: first the share of the PREVIOUS row's epilogue
     //   tap 2k+1: channels 0..3 of store group k;  tap 2k+2: channels 4..7 + pack/store
     // then this tap's LDS-DMA piece and residual load.
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                 constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;  // its LDS row relative to input row i
                 constexpr int KG = (t - 1) / 2;                  // store group served by taps 2k+1, 2k+2
                 constexpr bool EPI = !C::OUT_F32 && t >= 1 && KG < C::NST;
-                if constexpr (C::SPREAD) {
+                if constexpr (C::SPREAD || C::TIGHT) {
                     lds_wait<0>();
                 } else {
                     if constexpr (EPI && (t & 1)) epi_read(IntC<KG>{});
@@ -516,6 +521,16 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
                             constexpr int kr = ml - 1;
                             bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kr)]) ^ (unsigned)(C::kcl_of(kr) << 5));
                         }
+                    } else if constexpr (C::TIGHT) {
+                        if constexpr (ml == 0) {
+                            bq[nxt][0] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(0)]) ^ (unsigned)(C::kcl_of(0) << 5));
+                            bq[nxt][1] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(1)]) ^ (unsigned)(C::kcl_of(1) << 5));
+                        } else if constexpr (ml <= C::KC - 2) {
+                            constexpr int kr = ml + 1;
+                            bq[nxt][kr] = lds_read_b128((rowa[kyn] + rd[tn % 3][C::sub_of(kr)]) ^ (unsigned)(C::kcl_of(kr) << 5));
+                        }
+                        // staging read-back of the store group the next two taps finish, beside the third fragment
+                        if constexpr (ml == 2 && !C::OUT_F32 && (t % 2 == 0) && (t / 2 < C::NST)) epi_read(IntC<t / 2 + 0 * ml>{});
                     }
                     // micro-steps [ml*NS/MPT, (ml+1)*NS/MPT) of this tap
                     static_for<ml * NS / C::MPT, (ml + 1) * NS / C::MPT>([&](auto s_c) {
