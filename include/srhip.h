@@ -204,6 +204,16 @@ SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void);
 SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace,
                                   int n, int h, int w, int ci_pad, int ci_real, int ci_off, int w_i,
                                   int co_pad, int co_real, int accumulate, float scale, void* stream);
+/* The same with x and / or dz given as channel windows of wider NHWC bf16 maps (the layers of
+ * core/models/model_final.py:329-379 with more than 64 input or output channels, and their concatenated inputs, take one
+ * call per (<= 64 input, <= 64 output) channel pair without copying the slices out): the window of x is channels
+ * [x_coff, x_coff + ci_pad) of a map with x_cstride channels per pixel, likewise dz.  Offsets and strides are multiples
+ * of 8 channels.  A window may reach past its map's last channel (ci_real, co_real say how many channels count): what
+ * is read there only meets gradient entries that are not written. */
+SRHIP_API int srhip_conv3x3_wgrad_windows(const void* x, const void* dz, float* dw, float* db, void* workspace,
+                                          int n, int h, int w, int ci_pad, int ci_real, int ci_off, int w_i,
+                                          int co_pad, int co_real, int accumulate, float scale,
+                                          int x_cstride, int x_coff, int dz_cstride, int dz_coff, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Generic direct convolution (any kernel size / stride / padding, NHWC bf16,

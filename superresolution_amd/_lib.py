@@ -83,6 +83,7 @@ _SIGNATURES = {
     "srhip_conv_gemm_fwd": (c_int, [ctypes.POINTER(ConvGemmArgs), c_void_p]),
     "srhip_conv3x3_wgrad_workspace_bytes": (c_size_t, []),
     "srhip_conv3x3_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float, c_void_p]),
+    "srhip_conv3x3_wgrad_windows": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float] + [c_int] * 4 + [c_void_p]),
     "srhip_conv2d_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 +
                             [c_int, c_float, c_float, c_void_p]),
     "srhip_upsample_grid_bilinear_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

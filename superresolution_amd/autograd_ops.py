@@ -211,18 +211,6 @@ def _tile_channels(c: int) -> int:
     return 16 if c <= 16 else (32 if c <= 32 else 64)
 
 
-def _channel_slice(t: Tensor, c0: int, c1: int) -> Tensor:
-    """Channels [c0, c1) of an NHWC bf16 map as a contiguous map of 16, 32 or 64 channels (zero padded)."""
-    n = c1 - c0
-    width = _tile_channels(n)
-    if c0 == 0 and t.shape[-1] == width:
-        return t
-    out = torch.zeros(t.shape[:3] + (width,), dtype=t.dtype, device=t.device)
-    hi = min(c1, t.shape[-1])
-    out[..., :hi - c0] = t[..., c0:hi]
-    return out
-
-
 def _zero_insert2(dz: Tensor, h: int, w: int) -> Tensor:
     """(N,ho,wo,C) -> (N,h,w,C) with dz at the even positions: a stride-2 layer's output gradient seen from the
     stride-1 layer it is a 2x2 pick of (its data and weight gradients are that layer's on this tensor)."""
@@ -262,7 +250,8 @@ class _ConvAuto(Function):
         # is a shape the GEMM library serves three times slower than that)
         dw3 = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
         db = torch.zeros((cout,), dtype=torch.float32, device=w.device)
-        dz_slices = [(o, min(64, cout - o), _channel_slice(dzs, o, o + min(64, cout - o))) for o in range(0, cout, 64)]
+        # (the kernel reads the channel windows in place: no slice of x or dz is copied out)
+        dz_slices = [(o, min(64, cout - o)) for o in range(0, cout, 64)]
         k0 = 0
         for t in srcs:
             for a in range(0, t.shape[-1], 64):
@@ -270,10 +259,10 @@ class _ConvAuto(Function):
                 ci_real = min(ci, cin - (k0 + a))
                 if ci_real <= 0:
                     continue
-                xs = _channel_slice(t, a, a + ci)
-                for o, co, dzo in dz_slices:
+                for o, co in dz_slices:
                     # the bias gradient rides on the first input slice's launch (dz times ones on the MFMA pipe)
-                    F_.conv3x3_wgrad(xs, dzo, dw3[o:o + co], db[o:o + co] if k0 + a == 0 else None, ci_real, co, ci_off=k0 + a)
+                    F_.conv3x3_wgrad(t, dzs, dw3[o:o + co], db[o:o + co] if k0 + a == 0 else None, ci_real, co, ci_off=k0 + a,
+                                     x_window=(a, _tile_channels(ci)), dz_window=(o, _tile_channels(co)))
             k0 += t.shape[-1]
         dw = dw3 if k == 3 else dw3[:, :, 1:2, 1:2].contiguous()
         # ---- data gradient, cut into the sources

@@ -36,6 +36,8 @@ struct WgradParams {
     float* partial;
     int n, h, w;
     int nstrips, nsegs, seg_h, total_items;
+    // x and dz may be channel windows of wider maps: bytes per pixel of the map, byte offset of the window's first channel
+    int xs, xco, zs, zco;
 };
 
 constexpr int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
         const int y1 = min(y0 + p.seg_h, H);
         const int nout = y1 - y0;
 
-        const unsigned img_x = (unsigned)(H * W) * (unsigned)C::XPB;
-        const unsigned img_z = (unsigned)(H * W) * (unsigned)C::ZPB;
+        const unsigned img_x = (unsigned)(H * W) * (unsigned)p.xs;
+        const unsigned img_z = (unsigned)(H * W) * (unsigned)p.zs;
         const __amdgpu_buffer_rsrc_t rsrc_x =
             __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long long)n * img_x), 0, (int)img_x, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_z =
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
             const int c = (C::XPB == 128) ? (s ^ (((px >> 1) & 1) << 2)) : s;
             const int col = x0 - 1 + px;
             const bool ok = col >= 0 && col < W && px < C::TW + 2;
-            xoff[m] = ok ? (unsigned)(col * C::XPB + c * 16) : kOob;
+            xoff[m] = ok ? (unsigned)(col * p.xs + p.xco + c * 16) : kOob;
         }
 #pragma unroll
         for (int m = 0; m < C::MAXPZ; ++m) {
@@ -210,16 +212,16 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
             const int px = L / CPP, s = L % CPP;
             const int c = (C::ZPB == 128) ? (s ^ (((px >> 1) & 1) << 2)) : s;
             const int col = x0 + px;
-            zoff[m] = col < W ? (unsigned)(col * C::ZPB + c * 16) : kOob;
+            zoff[m] = col < W ? (unsigned)(col * p.zs + p.zco + c * 16) : kOob;
         }
         // x row r <-> image row y0 - 1 + r (r = 0 .. nout+1); dz row r <-> image row y0 + r.
         // Piece m (0 .. MAXPX+MAXPZ-1) of a row pair: x pieces first, then dz pieces; branch-free.
         auto x_soff = [&](const int r) {
             const int y = y0 - 1 + r;
             const bool in = (y >= 0) & (y < H) & (r < nout + 2);
-            return in ? (unsigned)(y * W) * (unsigned)C::XPB : kOob;
+            return in ? (unsigned)(y * W) * (unsigned)p.xs : kOob;
         };
-        auto z_soff = [&](const int r) { return (r < nout) ? (unsigned)((y0 + r) * W) * (unsigned)C::ZPB : kOob; };
+        auto z_soff = [&](const int r) { return (r < nout) ? (unsigned)((y0 + r) * W) * (unsigned)p.zs : kOob; };
         auto issue_piece = [&](auto m_c, const unsigned xsoff, const unsigned xslot, const unsigned zsoff, const unsigned zslot) {
             constexpr int m = decltype(m_c)::value;
             if constexpr (m < C::MAXPX) {
@@ -492,20 +494,26 @@ SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void)
     return (size_t)srhip_num_cus() * 4 * 10 * 1024 * sizeof(float);
 }
 
-SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,
-                                  int w, int ci_pad, int ci_real, int ci_off, int w_i, int co_pad, int co_real,
-                                  int accumulate, float scale, void* stream)
+SRHIP_API int srhip_conv3x3_wgrad_windows(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,
+                                          int w, int ci_pad, int ci_real, int ci_off, int w_i, int co_pad, int co_real,
+                                          int accumulate, float scale, int x_cstride, int x_coff, int dz_cstride, int dz_coff,
+                                          void* stream)
 {
     SRHIP_REQUIRE(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
     SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1, "conv3x3_wgrad: empty tensor");
     SRHIP_REQUIRE(ci_real >= 1 && ci_real <= ci_pad && co_real >= 1 && co_real <= co_pad, "conv3x3_wgrad: real channels exceed padded");
     SRHIP_REQUIRE(ci_off >= 0 && ci_off + ci_real <= w_i, "conv3x3_wgrad: input-channel window [%d,%d) outside the weight's %d", ci_off, ci_off + ci_real, w_i);
-    SRHIP_REQUIRE((long long)h * w * 64 * 2 < (1ll << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
+    SRHIP_REQUIRE(x_cstride >= 8 && x_cstride % 8 == 0 && x_coff >= 0 && x_coff % 8 == 0 && x_coff + ci_real <= x_cstride,
+                  "conv3x3_wgrad: x window [%d,%d) outside the map's %d channels (offsets and widths in multiples of 8)", x_coff, x_coff + ci_real, x_cstride);
+    SRHIP_REQUIRE(dz_cstride >= 8 && dz_cstride % 8 == 0 && dz_coff >= 0 && dz_coff % 8 == 0 && dz_coff + co_real <= dz_cstride,
+                  "conv3x3_wgrad: dz window [%d,%d) outside the map's %d channels (offsets and widths in multiples of 8)", dz_coff, dz_coff + co_real, dz_cstride);
+    SRHIP_REQUIRE((long long)h * w * (x_cstride > dz_cstride ? x_cstride : dz_cstride) * 2 < (1ll << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
     WgradParams p;
     p.x = (const char*)x;
     p.dz = (const char*)dz;
     p.partial = (float*)workspace;
     p.n = n; p.h = h; p.w = w;
+    p.xs = x_cstride * 2; p.xco = x_coff * 2; p.zs = dz_cstride * 2; p.zco = dz_coff * 2;
     hipStream_t s = (hipStream_t)stream;
 #define SRHIP_WGRAD_CASE(CI, CO) \
     if (ci_pad == CI && co_pad == CO) return launch_wgrad<WCfg<CI, CO>>(p, dw, db, w_i, ci_off, ci_real, co_real, accumulate, scale, s);
@@ -521,6 +529,14 @@ SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, floa
 #undef SRHIP_WGRAD_CASE
     srhip_set_error("conv3x3_wgrad: unsupported padded channels ci=%d co=%d (each must be 16, 32 or 64)", ci_pad, co_pad);
     return SRHIP_ERR_INVALID;
+}
+
+SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,
+                                  int w, int ci_pad, int ci_real, int ci_off, int w_i, int co_pad, int co_real,
+                                  int accumulate, float scale, void* stream)
+{
+    return srhip_conv3x3_wgrad_windows(x, dz, dw, db, workspace, n, h, w, ci_pad, ci_real, ci_off, w_i, co_pad, co_real, accumulate, scale,
+                                       ci_pad, 0, co_pad, 0, stream);
 }
 
 }  // extern "C"

@@ -259,9 +259,12 @@ def _wgrad_workspace(device) -> torch.Tensor:
 
 
 def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], ci_real: int,
-                  co_real: int, ci_off: int = 0, accumulate: bool = False, scale: float = 1.0) -> None:
+                  co_real: int, ci_off: int = 0, accumulate: bool = False, scale: float = 1.0,
+                  x_window=None, dz_window=None) -> None:
     """dw[:, ci_off:ci_off+ci_real] (=|+=) weight gradient of a 3x3 layer from its input x (N,H,W,ci_pad) and the
-    gradient dz (N,H,W,co_pad) of its pre-activation output; db (=|+=) bias gradient (or None)."""
+    gradient dz (N,H,W,co_pad) of its pre-activation output; db (=|+=) bias gradient (or None).
+    x_window / dz_window = (first_channel, tile) read channels [first_channel, first_channel + tile) of a wider map in
+    place (tile 16, 32 or 64; it may reach past the map's last channel, ci_real / co_real say how many channels count)."""
     x = _req(x, torch.bfloat16, "x")
     dz = _req(dz, torch.bfloat16, "dz")
     if x.shape[:3] != dz.shape[:3]:
@@ -273,9 +276,16 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw: torch.Tensor, db: Optio
     if db is not None and (db.dtype != torch.float32 or db.numel() < co_real):
         raise ValueError("conv3x3_wgrad: db must be fp32[co_real]")
     n, h, w, ci_pad = x.shape
-    check(lib.srhip_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _ptr(db), _wgrad_workspace(x.device).data_ptr(),
-                                  n, h, w, ci_pad, ci_real, ci_off, dw.shape[1], dz.shape[3], co_real, int(accumulate),
-                                  scale, _stream()))
+    if x_window is None and dz_window is None:
+        check(lib.srhip_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _ptr(db), _wgrad_workspace(x.device).data_ptr(),
+                                      n, h, w, ci_pad, ci_real, ci_off, dw.shape[1], dz.shape[3], co_real, int(accumulate),
+                                      scale, _stream()))
+        return
+    xo, xt = (0, ci_pad) if x_window is None else x_window
+    zo, zt = (0, dz.shape[3]) if dz_window is None else dz_window
+    check(lib.srhip_conv3x3_wgrad_windows(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _ptr(db), _wgrad_workspace(x.device).data_ptr(),
+                                          n, h, w, xt, ci_real, ci_off, dw.shape[1], zt, co_real, int(accumulate), scale,
+                                          ci_pad, xo, dz.shape[3], zo, _stream()))
 
 
 def relu_mask(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

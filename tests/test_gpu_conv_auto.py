@@ -123,3 +123,40 @@ def test_concatenated_sources_are_read_in_place(chs, cout, stride):
         assert (got.float() - ref.float()).abs().max().item() <= 2e-2
     with pytest.raises(ValueError):
         F_.conv2d_auto((xs[0], xs[0][:, :-1]), wt, b)
+
+
+@pytest.mark.parametrize("case", [
+    # (x channels, x window, ci_real, dz channels, dz window, co_real)
+    (112, (64, 64), 48, 160, (128, 32), 32),
+    (160, (64, 64), 64, 64, (0, 64), 64),
+    (48, (0, 64), 48, 96, (64, 32), 32),      # the window of x reaches past the map's last channel
+    (32, (16, 16), 16, 16, (0, 16), 3),
+])
+def test_weight_gradient_reads_channel_windows_in_place(case):
+    """srhip_conv3x3_wgrad_windows on channel windows of wider maps == srhip_conv3x3_wgrad on zero-padded copies of the
+    windows, bit for bit, bias gradient included: what a window reads past its real channels only meets entries of the
+    gradient that are not written."""
+    from superresolution_amd import functional as F_
+    cx, (xo, xt), ci_real, cz, (zo, zt), co_real = case
+    g = torch.Generator().manual_seed(cx + cz)
+    n, h, w = 2, 37, 150
+    x = torch.relu(torch.randn(n, h, w, cx, generator=g)).to(torch.bfloat16).cuda()
+    dz = (torch.randn(n, h, w, cz, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    w_i = ci_real + 5
+
+    def padded(t, o, tile, real):
+        out = torch.zeros(n, h, w, tile, dtype=torch.bfloat16, device="cuda")
+        out[..., :real] = t[..., o:o + real]
+        return out
+
+    ref_dw = torch.full((co_real, w_i, 3, 3), 7.0, device="cuda")
+    ref_db = torch.zeros(co_real, device="cuda")
+    F_.conv3x3_wgrad(padded(x, xo, xt, ci_real), padded(dz, zo, zt, co_real), ref_dw, ref_db, ci_real, co_real, ci_off=5)
+    got_dw = torch.full((co_real, w_i, 3, 3), 7.0, device="cuda")
+    got_db = torch.zeros(co_real, device="cuda")
+    F_.conv3x3_wgrad(x, dz, got_dw, got_db, ci_real, co_real, ci_off=5, x_window=(xo, xt), dz_window=(zo, zt))
+    assert torch.equal(got_dw, ref_dw) and torch.equal(got_db, ref_db)
+    assert float(got_dw[:, :5].min()) == 7.0 and float(got_dw[:, :5].max()) == 7.0       # outside [ci_off, ci_off + ci_real): untouched
+    assert float(got_dw[:, 5:].abs().max()) > 0.0
+    with pytest.raises(RuntimeError):
+        F_.conv3x3_wgrad(x, dz, got_dw, got_db, ci_real, co_real, ci_off=5, x_window=(cx, xt), dz_window=(zo, zt))
