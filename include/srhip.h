@@ -353,6 +353,12 @@ SRHIP_API int srhip_gradient_map_unshuffle4_nhwc_bf16(const float* src, int src_
  * channel k*16 + i*4 + j -> dst (N,4h,4w,16) bf16 NHWC with channels k < c real and the rest zero (the padded input of
  * the next layer).  c <= 4.  A permutation: bit-exact. */
 SRHIP_API int srhip_pixel_shuffle4_nhwc_bf16_to_nhwc16(const void* src, void* dst, int n, int c, int h, int w, int cstride, void* stream);
+/* The whole tail nn.PixelShuffle(4) -> nn.Conv2d(3, 3, 3, 1, 1) -> activation of core/models/model_final.py:446-449 in
+ * one pass: src (N,h,w,cstride >= 48) bf16 NHWC, channel k*16 + i*4 + j; weight fp32 (3,3,3,3) OIHW and bias fp32[3]
+ * (or NULL) in device memory, used as they are (fp32 arithmetic); dst (N,3,4h,4w) fp32 NCHW.
+ * act 0 none, 1 ReLU, 2 LeakyReLU(slope). */
+SRHIP_API int srhip_pixel_shuffle4_conv3x3_c3_nchw_f32(const void* src, const float* weight, const float* bias, float* dst, int n,
+                                                       int h, int w, int cstride, int act, float slope, void* stream);
 /* Fused network head: NHWC bf16 (N,H,W,cstride>=c*r*r) -> NCHW fp32 (N,c,H*r,W*r). */
 SRHIP_API int srhip_pixel_shuffle_nhwc_to_nchw_f32(const void* src, float* dst, int n, int c, int h,
                                                    int w, int r, int cstride, void* stream);

@@ -983,6 +983,80 @@ __global__ void pixel_shuffle4_nhwc_bf16_to_nhwc16_kernel(const unsigned short* 
     }
 }
 
+// The tail of the temporal network (core/models/model_final.py:446-449: PixelShuffle(4) -> Conv2d(3, 3, 3, 1, 1) -> ReLU)
+// in one pass: src (N,h,w,cs >= 48) bf16 NHWC, channel k*16 + i*4 + j = colour k of output pixel (4y+i, 4x+j);
+// dst (N,3,4h,4w) fp32 NCHW = act(conv3x3(shuffled) + bias).  The shuffled image never exists: a work-group stages an
+// 8 x 32 tile of input pixels (plus one pixel of halo, zeros outside the image = the convolution's zero padding) in
+// LDS; one item = one input pixel and sub-row i = four output pixels of one row x three colours, whose 3 x 6 x 3
+// neighbourhood is nine 8-byte LDS reads plus the two neighbours per row; fp32 weights, fp32 arithmetic (81 fused
+// multiply-adds per output pixel on the vector ALU: 150 MB of traffic instead of the 900 MB of the 16-channel padded
+// detour through the MFMA kernel).
+constexpr int kTailLX = 32, kTailLY = 8;
+__global__ __launch_bounds__(256) void pixel_shuffle4_conv3x3_c3_kernel(const unsigned short* __restrict__ src, const float* __restrict__ wgt,
+                                                                       const float* __restrict__ bias, float* __restrict__ dst, int n, int h,
+                                                                       int w, int cs, float slope)
+{
+    __shared__ uint4 tile[(kTailLY + 2) * (kTailLX + 2) * 6];
+    const unsigned short* ts = (const unsigned short*)tile;
+    const int tiles_x = (w + kTailLX - 1) / kTailLX, tiles_y = (h + kTailLY - 1) / kTailLY;
+    const long long ntiles = (long long)n * tiles_y * tiles_x;
+    const long long HW = 16ll * h * w;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const long long img = t / ((long long)tiles_x * tiles_y);
+        for (int it = threadIdx.x; it < (kTailLY + 2) * (kTailLX + 2) * 6; it += blockDim.x) {
+            const int chunk = it % 6, px = it / 6;
+            const int X = tx * kTailLX - 1 + px % (kTailLX + 2), Y = ty * kTailLY - 1 + px / (kTailLX + 2);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (X >= 0 && X < w && Y >= 0 && Y < h) v = *(const uint4*)(src + ((img * h + Y) * w + X) * cs + chunk * 8);
+            tile[it] = v;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < kTailLY * kTailLX * 4; it += blockDim.x) {
+            const int lx = it % kTailLX, r = it / kTailLX, i = r & 3, ly = r >> 2;
+            const int X = tx * kTailLX + lx, Y = ty * kTailLY + ly;
+            if (X >= w || Y >= h) continue;
+            float acc[3][4];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                const float b = bias != nullptr ? bias[co] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[co][j] = b;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int ii = i + ky - 1;
+                const int lyy = ly + 1 + (ii < 0 ? -1 : (ii > 3 ? 1 : 0));
+                const int base = (lyy * (kTailLX + 2) + lx + 1) * 48 + (ii & 3) * 4;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const uint2 m = *(const uint2*)(ts + base + ci * 16);
+                    float v[6];
+                    v[0] = bf16_bits_to_f32(ts[base + ci * 16 - 48 + 3]);
+                    v[1] = bf16_lo(m.x); v[2] = bf16_hi(m.x); v[3] = bf16_lo(m.y); v[4] = bf16_hi(m.y);
+                    v[5] = bf16_bits_to_f32(ts[base + ci * 16 + 48]);
+#pragma unroll
+                    for (int co = 0; co < 3; ++co)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float wv = wgt[((co * 3 + ci) * 3 + ky) * 3 + kx];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[co][j] = __builtin_fmaf(wv, v[j + kx], acc[co][j]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaxf(acc[co][j], acc[co][j] * slope);   // act(t) = max(t, slope * t)
+                *(float4*)(dst + (img * 3 + co) * HW + (4ll * Y + i) * (4ll * w) + 4ll * X) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // GPT = channel groups (of 8) per thread: with 2 the motion-vector and tap arithmetic (two IEEE divisions, ~150 vector
 // instructions) is paid once per 32 bytes of output instead of once per 16.
 template <int GPT>
@@ -2149,6 +2223,22 @@ SRHIP_API int srhip_gradient_map_unshuffle4_nhwc_bf16(const float* src, int src_
     hipLaunchKernelGGL(gradient_map_unshuffle4_nhwc_bf16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds,
                        (hipStream_t)stream, src, (unsigned short*)dst, n, src_planes, gp, nplanes, h, w, eps);
     return srhip_check_launch("gradient_map_unshuffle4_nhwc_bf16");
+}
+
+SRHIP_API int srhip_pixel_shuffle4_conv3x3_c3_nchw_f32(const void* src, const float* weight, const float* bias, float* dst, int n,
+                                                       int h, int w, int cstride, int act, float slope, void* stream)
+{
+    SRHIP_REQUIRE(src && weight && dst, "pixel_shuffle4_conv3x3_c3_nchw_f32: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cstride >= 48 && cstride % 8 == 0,
+                  "pixel_shuffle4_conv3x3_c3_nchw_f32: input pixels of at least 48 channels (a multiple of 8)");
+    SRHIP_REQUIRE((size_t)src % 16 == 0 && (size_t)dst % 16 == 0, "pixel_shuffle4_conv3x3_c3_nchw_f32: 16-byte aligned tensors");
+    SRHIP_REQUIRE(act >= 0 && act <= 2, "pixel_shuffle4_conv3x3_c3_nchw_f32: act must be 0 (none), 1 (ReLU) or 2 (LeakyReLU)");
+    const float s = act == 0 ? 1.0f : (act == 1 ? 0.0f : slope);
+    const long long ntiles = (long long)n * srhip_div_up(h, kTailLY) * srhip_div_up(w, kTailLX);
+    const long long cap = (long long)srhip_num_cus() * 8;
+    hipLaunchKernelGGL(pixel_shuffle4_conv3x3_c3_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, weight, bias, dst, n, h, w, cstride, s);
+    return srhip_check_launch("pixel_shuffle4_conv3x3_c3_nchw_f32");
 }
 
 SRHIP_API int srhip_pixel_shuffle4_nhwc_bf16_to_nhwc16(const void* src, void* dst, int n, int c, int h, int w, int cstride, void* stream)

@@ -806,6 +806,25 @@ def pixel_shuffle4_nhwc_to_nhwc16(x: torch.Tensor, c: int) -> torch.Tensor:
     return out
 
 
+def pixel_shuffle4_conv3x3_c3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+                              slope: float = 0.0) -> torch.Tensor:
+    """act(conv2d(pixel_shuffle(x, 4), weight, bias, padding=1)) for a 3 -> 3 channel 3x3 layer, in one pass:
+    x (N,h,w,>=48) bf16 NHWC -> (N,3,4h,4w) fp32 NCHW; fp32 weights and arithmetic."""
+    x = _req(x, torch.bfloat16, "x")
+    weight = _req(weight, torch.float32, "weight")
+    if tuple(weight.shape) != (3, 3, 3, 3) or x.shape[-1] < 48:
+        raise ValueError("pixel_shuffle4_conv3x3_c3: a (3,3,3,3) weight and at least 48 input channels")
+    if bias is not None:
+        bias = _req(bias, torch.float32, "bias")
+        if bias.numel() != 3:
+            raise ValueError("pixel_shuffle4_conv3x3_c3: bias must have 3 elements")
+    n, h, w, cs = x.shape
+    out = torch.empty((n, 3, 4 * h, 4 * w), dtype=torch.float32, device=x.device)
+    check(lib.srhip_pixel_shuffle4_conv3x3_c3_nchw_f32(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), n, h, w, cs,
+                                                       act, slope, _stream()))
+    return out
+
+
 def pixel_shuffle_nhwc_to_nchw_f32(x: torch.Tensor, c: int, r: int) -> torch.Tensor:
     x = _req(x, torch.bfloat16, "x")
     n, h, w, cs = x.shape

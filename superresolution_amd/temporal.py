@@ -364,12 +364,15 @@ class SuperSampler(nn.Module):
             assert depth_max < 10, "Depth value is too large"
             return sr_frame, enhance_weight
         t = F_.conv2d_auto((fmap, fmap_shadow), c0.weight, c0.bias)
-        if self.sr_scale == 4 and self.frame_ch <= 4:   # PixelShuffle straight into the last layer's padded input layout
-            hr16 = F_.pixel_shuffle4_nhwc_to_nhwc16(t, self.frame_ch)
+        if self.sr_scale == 4 and self.frame_ch == 3:   # PixelShuffle, the last 3 -> 3 layer and its ReLU in one pass
+            sr_frame = F_.pixel_shuffle4_conv3x3_c3(t, c2.weight.detach().float(), c2.bias.detach().float(), act=F_.ACT_RELU)
         else:
-            hr16 = F_.nchw_f32_to_nhwc_bf16(F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale))
-        wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)
-        sr_frame = F_.conv3x3(hr16, wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)
+            if self.sr_scale == 4 and self.frame_ch <= 4:   # PixelShuffle straight into the last layer's padded input layout
+                hr16 = F_.pixel_shuffle4_nhwc_to_nhwc16(t, self.frame_ch)
+            else:
+                hr16 = F_.nchw_f32_to_nhwc_bf16(F_.pixel_shuffle_nhwc_to_nchw_f32(t, self.frame_ch, self.sr_scale))
+            wp = F_.conv3x3_pack_weights(c2.weight.detach(), self.frame_ch, 16)
+            sr_frame = F_.conv3x3(hr16, wp, c2.bias.detach(), self.frame_ch, act=F_.ACT_RELU, out_nchw_f32=True)
 
         # model_final.py:464; the comparison waits for the device, so it runs once every launch of the pass is queued
         assert depth_max < 10, "Depth value is too large"

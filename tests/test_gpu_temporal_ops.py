@@ -281,3 +281,23 @@ def test_pixel_shuffle_into_the_padded_nhwc_layout_is_a_permutation(F_, shape, c
     assert not got[..., c:].any()
     with pytest.raises(ValueError):
         F_.pixel_shuffle4_nhwc_to_nhwc16(x, 5)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 7, 48), (2, 19, 45, 48), (1, 136, 240, 64), (1, 8, 32, 48), (1, 1, 1, 48)])
+def test_fused_tail_pixel_shuffle_conv_relu(F_, shape):
+    """PixelShuffle(4) -> Conv2d(3,3,3,1,1) -> ReLU (core/models/model_final.py:446-449) in one pass against torch's own
+    fp32 operators on the same bf16 map (tile borders, image borders, partial tiles): fp32 accumulation bar."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(shape[1] * 7 + shape[2])
+    x = torch.randn(*shape, generator=g).to(torch.bfloat16)
+    wgt = torch.randn(3, 3, 3, 3, generator=g) * 0.3
+    bias = torch.randn(3, generator=g) * 0.1
+    for act, fn in ((F_.ACT_RELU, torch.relu), (F_.ACT_NONE, lambda v: v)):
+        got = F_.pixel_shuffle4_conv3x3_c3(x.cuda(), wgt.cuda(), bias.cuda(), act=act)
+        ref = fn(TF.conv2d(TF.pixel_shuffle(x[..., :48].float().permute(0, 3, 1, 2), 4), wgt, bias, padding=1))
+        assert got.shape == ref.shape and got.dtype == torch.float32
+        assert float((got.cpu() - ref).abs().max()) <= 1e-4
+    got = F_.pixel_shuffle4_conv3x3_c3(x.cuda(), wgt.cuda(), None)
+    assert float((got.cpu() - TF.conv2d(TF.pixel_shuffle(x[..., :48].float().permute(0, 3, 1, 2), 4), wgt, None, padding=1)).abs().max()) <= 1e-4
+    with pytest.raises(ValueError):
+        F_.pixel_shuffle4_conv3x3_c3(x.cuda(), wgt[:2].cuda(), bias.cuda())
