@@ -342,6 +342,13 @@ SRHIP_API int srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16_max(const float* src,
                                                                float* block_max, int max_cap, void* stream);
 SRHIP_API int srhip_pixel_unshuffle(const void* src, void* dst, int n, int c, int h, int w, int r,
                                     int elem_size, void* stream);
+/* GradientMap + PixelUnshuffle(4) (core/models/model_final.py:160-187,406-409) + the layout conversion in front of the
+ * convolution that consumes them, one pass: src (N,src_planes,4h,4w) fp32 NCHW, planes[0..nplanes) (HOST array) the
+ * plane indices taken in order -> dst (N,h,w,16*nplanes) bf16 NHWC, channel k*16 + i*4 + j = gradient magnitude of plane
+ * planes[k] at (4y+i, 4x+j).  Equal bit for bit to srhip_gradient_map_f32 on those planes followed by
+ * srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16.  nplanes <= 23. */
+SRHIP_API int srhip_gradient_map_unshuffle4_nhwc_bf16(const float* src, int src_planes, const int* planes, int nplanes, void* dst, int n,
+                                                      int h, int w, float eps, void* stream);
 /* nn.PixelShuffle(4) between two convolutions (core/models/model_final.py:446-448): src (N,h,w,cstride >= 16c) bf16 NHWC,
  * channel k*16 + i*4 + j -> dst (N,4h,4w,16) bf16 NHWC with channels k < c real and the rest zero (the padded input of
  * the next layer).  c <= 4.  A permutation: bit-exact. */

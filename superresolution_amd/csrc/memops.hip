@@ -884,6 +884,80 @@ __global__ void gradient_map_rows4_kernel(const float* __restrict__ src, float* 
     *(float4*)(dst + (long long)blockIdx.z * h * w + y * w + x0) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// GradientMap followed by PixelUnshuffle(4) and the NHWC bf16 conversion (core/models/model_final.py:406-409 feeds the
+// result to a convolution): out[n][y][x][k*16 + i*4 + j] = bf16(gradient of plane planes[k] of image n at (4y+i, 4x+j)).
+// The block / LDS organisation of pixel_unshuffle4_nchw_f32_to_nhwc_bf16_kernel; every item computes the sixteen
+// gradients of one output pixel's 4 x 4 block of one plane from six 16-byte row loads and the two neighbours per row, in
+// the order of additions of gradient_map_rows4_kernel, so the result equals the two passes in sequence bit for bit.
+struct GradPlanes { int idx[24]; };
+__global__ __launch_bounds__(256) void gradient_map_unshuffle4_nhwc_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                               int n, int src_planes, GradPlanes planes, int c, int h,
+                                                                               int w, float eps)
+{
+    extern __shared__ uint4 tile[];
+    uint2* t2 = (uint2*)tile;
+    const int nq = c * 4, q = nq + 2, cg = c * 2;
+    const long long total = (long long)n * h * w;
+    const long long ntiles = (total + kLayoutTile - 1) / kLayoutTile;
+    const int H = 4 * h, W = 4 * w;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long p0 = t * kLayoutTile;
+        const int npx = (int)(total - p0 < kLayoutTile ? total - p0 : kLayoutTile);
+        // one item = (pixel, plane): the six input rows around the pixel's 4 x 4 block are loaded once for its four rows
+        for (int it = threadIdx.x; it < kLayoutTile * c; it += blockDim.x) {
+            const int px = it & (kLayoutTile - 1), k = it / kLayoutTile;
+            if (px < npx) {
+                const long long p = p0 + px;
+                const int x = (int)(p % w);
+                const long long r = p / w;
+                const int y = (int)(r % h);
+                const long long img = r / h;
+                const float* pl = src + (img * src_planes + planes.idx[k]) * (long long)H * W;
+                const int x0 = 4 * x;
+                float v[6][6];
+#pragma unroll
+                for (int ry = 0; ry < 6; ++ry) {
+                    const int yy = 4 * y + ry - 1;
+                    if (yy < 0 || yy >= H) {
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) v[ry][e] = 0.0f;
+                    } else {
+                        const float* row = pl + (long long)yy * W;
+                        const float4 m = *(const float4*)(row + x0);
+                        v[ry][0] = x0 > 0 ? row[x0 - 1] : 0.0f;
+                        v[ry][1] = m.x; v[ry][2] = m.y; v[ry][3] = m.z; v[ry][4] = m.w;
+                        v[ry][5] = x0 + 4 < W ? row[x0 + 4] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float gv = 0.0f, gh = 0.0f;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                gv += (float)(ky - 1) * v[i + ky][j + kx];
+                                gh += (float)(kx - 1) * v[i + ky][j + kx];
+                            }
+                        o[j] = sqrtf(gv * gv + gh * gh + eps);
+                    }
+                    t2[px * q + k * 4 + i] = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                }
+            }
+        }
+        __syncthreads();
+        uint4* out = (uint4*)(dst + p0 * (16ll * c));
+        for (int it = threadIdx.x; it < npx * cg; it += blockDim.x) {
+            const int px = it / cg, g = it - px * cg;
+            out[it] = *(const uint4*)(t2 + px * q + 2 * g);
+        }
+        __syncthreads();
+    }
+}
+
 // PixelShuffle(4) of an NHWC bf16 map written as the NHWC bf16 input of the next convolution, c <= 4 real channels in a
 // 16-channel pixel (core/models/model_final.py:446-448: conv -> PixelShuffle -> conv): out[n][4y+i][4x+j][k] =
 // in[n][y][x][k*16 + i*4 + j] for k < c, zero for k >= c.  One lane = one 16-byte half of an output pixel (the stores of a
@@ -2127,6 +2201,28 @@ SRHIP_API int srhip_gradient_map_f32(const float* src, float* dst, int planes, i
         hipLaunchKernelGGL(gradient_map_kernel, dim3(grid_for((long long)planes * h * w, srhip_num_cus())), dim3(kThreads), 0,
                            (hipStream_t)stream, src, dst, (long long)planes, h, w, eps);
     return srhip_check_launch("gradient_map_f32");
+}
+
+SRHIP_API int srhip_gradient_map_unshuffle4_nhwc_bf16(const float* src, int src_planes, const int* planes, int nplanes, void* dst, int n,
+                                                      int h, int w, float eps, void* stream)
+{
+    SRHIP_REQUIRE(src && dst && planes, "gradient_map_unshuffle4_nhwc_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1 && src_planes >= 1, "gradient_map_unshuffle4_nhwc_bf16: bad shape");
+    SRHIP_REQUIRE(nplanes >= 1 && nplanes <= 23, "gradient_map_unshuffle4_nhwc_bf16: 1 to 23 planes (got %d)", nplanes);
+    SRHIP_REQUIRE((size_t)src % 16 == 0 && (size_t)dst % 16 == 0, "gradient_map_unshuffle4_nhwc_bf16: 16-byte aligned tensors");
+    SRHIP_REQUIRE((long long)h * w * 16 < (1ll << 31), "gradient_map_unshuffle4_nhwc_bf16: at most 2^31 pixels per plane");
+    GradPlanes gp;
+    for (int k = 0; k < 24; ++k) gp.idx[k] = 0;
+    for (int k = 0; k < nplanes; ++k) {
+        SRHIP_REQUIRE(planes[k] >= 0 && planes[k] < src_planes, "gradient_map_unshuffle4_nhwc_bf16: plane index %d outside the tensor", planes[k]);
+        gp.idx[k] = planes[k];
+    }
+    const size_t lds = (size_t)kLayoutTile * (nplanes * 4 + 2) * sizeof(uint2);
+    const long long ntiles = ((long long)n * h * w + kLayoutTile - 1) / kLayoutTile;
+    const long long cap = (long long)srhip_num_cus() * 16;
+    hipLaunchKernelGGL(gradient_map_unshuffle4_nhwc_bf16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds,
+                       (hipStream_t)stream, src, (unsigned short*)dst, n, src_planes, gp, nplanes, h, w, eps);
+    return srhip_check_launch("gradient_map_unshuffle4_nhwc_bf16");
 }
 
 SRHIP_API int srhip_pixel_shuffle4_conv3x3_c3_nchw_f32(const void* src, const float* weight, const float* bias, float* dst, int n,

@@ -6,6 +6,7 @@ own device memory and to name the current HIP stream.  NHWC tensors are plain co
 """
 from typing import Optional
 
+import ctypes
 import os
 
 import torch
@@ -774,6 +775,22 @@ def pixel_unshuffle_to_nhwc_bf16(x: torch.Tensor, r: int, want_max: bool = False
                                                                    part.data_ptr(), part.numel(), _stream()))
         return out, part.max()
     check(lib.srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16(x.data_ptr(), out.data_ptr(), n, c, hr // 4, wr // 4, _stream()))
+    return out
+
+
+def gradient_map_unshuffle_nhwc(x: torch.Tensor, planes, eps: float = 1e-6) -> torch.Tensor:
+    """nchw_f32_to_nhwc_bf16(pixel_unshuffle(gradient_map(x[:, planes]), 4)) in one pass (GradientMap + PixelUnshuffle of
+    core/models/model_final.py:406-409): x (N,C,4h,4w) fp32 -> (N,h,w,16*len(planes)) bf16."""
+    x = _req(x, torch.float32, "x")
+    n, cs, hr, wr = x.shape
+    planes = [int(k) for k in planes]
+    if hr % 4 or wr % 4:
+        raise ValueError("gradient_map_unshuffle_nhwc: spatial size not divisible by 4")
+    if not 1 <= len(planes) <= 23 or any(k < 0 or k >= cs for k in planes):
+        raise ValueError("gradient_map_unshuffle_nhwc: 1 to 23 plane indices inside the tensor")
+    out = torch.empty((n, hr // 4, wr // 4, 16 * len(planes)), dtype=torch.bfloat16, device=x.device)
+    idx = (ctypes.c_int * len(planes))(*planes)
+    check(lib.srhip_gradient_map_unshuffle4_nhwc_bf16(x.data_ptr(), cs, idx, len(planes), out.data_ptr(), n, hr // 4, wr // 4, eps, _stream()))
     return out
 
 

@@ -262,12 +262,16 @@ class MainNetwork(nn.Module):
 
     def run(self, fmap_current: Tensor, fmap_history: Tensor, fmap_gbuffer: Tensor, hr_buffer: Tensor) -> Tensor:
         # normal and base-colour planes (model_final.py:417); each range is contiguous per sample, so no copy is made
-        nb, _, hh, ww = hr_buffer.shape
-        gfull = torch.empty((nb, 6, hh, ww), dtype=torch.float32, device=hr_buffer.device)
-        for i in range(nb):
-            F_.gradient_map(hr_buffer[i:i + 1, 0:3], self.grad_map[0].eps, out=gfull[i:i + 1, 0:3])
-            F_.gradient_map(hr_buffer[i:i + 1, 6:9], self.grad_map[0].eps, out=gfull[i:i + 1, 3:6])
-        grad, g_self, g_cross = self.attn_grad.run(F_.pixel_unshuffle_to_nhwc_bf16(gfull, self.sr_scale))
+        if self.sr_scale == 4:   # gradient map, PixelUnshuffle and the layout conversion in one pass over the six planes
+            folded = F_.gradient_map_unshuffle_nhwc(hr_buffer, (0, 1, 2, 6, 7, 8), self.grad_map[0].eps)
+        else:
+            nb, _, hh, ww = hr_buffer.shape
+            gfull = torch.empty((nb, 6, hh, ww), dtype=torch.float32, device=hr_buffer.device)
+            for i in range(nb):
+                F_.gradient_map(hr_buffer[i:i + 1, 0:3], self.grad_map[0].eps, out=gfull[i:i + 1, 0:3])
+                F_.gradient_map(hr_buffer[i:i + 1, 6:9], self.grad_map[0].eps, out=gfull[i:i + 1, 3:6])
+            folded = F_.pixel_unshuffle_to_nhwc_bf16(gfull, self.sr_scale)
+        grad, g_self, g_cross = self.attn_grad.run(folded)
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
         if torch.is_grad_enabled():   # model_final.py:422 as written, on the bf16 maps (gates broadcast over the channels)
             cur = fmap_current + torch.sigmoid(f_self * g_cross) * fmap + torch.sigmoid(g_self * f_cross) * grad

@@ -254,6 +254,21 @@ def test_disocclusion_with_spare_auxiliary_planes_and_in_place_depth_clamp(F_):
         F_.clamp_depth(want, out=want[:, ::2])
 
 
+@pytest.mark.parametrize("shape", [(1, 10, 16, 24), (2, 10, 20, 52), (1, 10, 544, 960), (3, 4, 4, 4)])
+def test_fused_gradient_map_unshuffle_bit_exact(F_, shape):
+    """GradientMap + PixelUnshuffle(4) + NHWC bf16 conversion in one pass == the three kernels in sequence, bit for bit
+    (image borders, 64-pixel tiles that straddle rows and images, planes taken out of order)."""
+    rng = np.random.default_rng(sum(shape))
+    x = dev(rng.standard_normal(shape).astype(np.float32))
+    for planes in ((0, 1, 2, 6, 7, 8), (3,), (2, 0)):
+        planes = tuple(k % shape[1] for k in planes)
+        got = F_.gradient_map_unshuffle_nhwc(x, planes, 1e-6)
+        ref = F_.pixel_unshuffle_to_nhwc_bf16(F_.gradient_map(x[:, list(planes)].contiguous(), 1e-6), 4)
+        assert got.shape == ref.shape and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    with pytest.raises(ValueError):
+        F_.gradient_map_unshuffle_nhwc(x, (shape[1],))
+
+
 @pytest.mark.parametrize("shape,c", [((1, 5, 7, 48), 3), ((2, 9, 4, 64), 4), ((1, 136, 240, 48), 3), ((1, 3, 3, 16), 1)])
 def test_pixel_shuffle_into_the_padded_nhwc_layout_is_a_permutation(F_, shape, c):
     """PixelShuffle(4) between two convolutions without the fp32 NCHW detour: equal bit for bit to the fused NHWC -> NCHW
