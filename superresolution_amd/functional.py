@@ -389,7 +389,8 @@ def _cached_pack(weight: torch.Tensor, tag, build) -> torch.Tensor:
         return hit[2]
     packed = build()
     try:
-        ref = weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None))
+        # (bound to the dict itself: at interpreter shutdown the module's globals are cleared before the last tensors die)
+        ref = weakref.ref(weight, lambda _r, k=key, cache=_pack_cache: cache.pop(k, None))
     except TypeError:
         return packed
     _pack_cache[key] = (ref, (weight._version, weight.data_ptr()), packed)
