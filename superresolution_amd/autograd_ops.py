@@ -229,6 +229,13 @@ class _ConvAuto(Function):
 
     @staticmethod
     def forward(ctx, weight: Tensor, bias: Tensor, stride: int, padding: int, act: int, *srcs: Tensor):
+        k = weight.shape[-1]
+        if bias is None:
+            raise ValueError("autograd_ops.conv2d: a bias tensor is required (every layer of the path has one)")
+        if weight.shape[-2] != k or k not in (1, 3) or padding != k // 2 or stride not in (1, 2):
+            raise ValueError(f"autograd_ops.conv2d: differentiable layers are kernel 1 or 3 with padding kernel // 2 and "
+                             f"stride 1 or 2 (the backward derives its data gradient from that); got kernel "
+                             f"{tuple(weight.shape[-2:])}, stride {stride}, padding {padding}")
         w = weight.detach().float().contiguous()
         y = F_.conv2d_auto(tuple(srcs) if len(srcs) > 1 else srcs[0], w, bias.detach().float().contiguous(), stride=stride,
                            padding=padding, act=act)

@@ -11,8 +11,13 @@ reducer (``attach``: the default network's hand-written backward) writes each we
 straight into its view, tells the reducer (``mark_ready``), and the reducer starts the asynchronous
 all-reduce of a bucket as soon as its last gradient has been queued, so the collective runs on the
 communication stream beside the rest of the backward pass.  ``all_reduce()`` after backward starts
-whatever is still pending, waits, and applies the 1/world factor to the buffer once.
+whatever is still pending, waits, applies the 1/world factor to the buffer once and re-arms the
+buckets for the next step (however the caller zeroes the gradients).  Several backward passes per
+optimiser step (gradient accumulation) run all but the last under ``no_sync()``; a backward that
+starts while a bucket's collective is already in flight is refused, because it would add local
+gradients to a partly reduced buffer.
 """
+import contextlib
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -73,6 +78,8 @@ class FlatGradAllReducer:
         self._ready = [False] * len(self.params)
         self._works: List[Optional[object]] = [None] * self.n_buckets
         self._launched = [False] * self.n_buckets
+        self._defer = False               # inside no_sync(): mark_ready records, nothing is started
+        self._log_stale = False           # launch_log belongs to a finished step: cleared by the next launch
         self.launch_log: List[int] = []   # buckets in the order their collective was started (tests, profiling)
 
     # ------------------------------------------------------------------ bookkeeping
@@ -102,11 +109,43 @@ class FlatGradAllReducer:
                 p.grad = None
         else:
             self.flat.zero_()
+        self._wait_all()
+        self._rearm()
+        self.launch_log = []
+        self._log_stale = False
+
+    def _rearm(self) -> None:
         self._left = list(self._pending)
         self._ready = [False] * len(self.params)
-        self._works = [None] * self.n_buckets
         self._launched = [False] * self.n_buckets
-        self.launch_log = []
+
+    def _wait_all(self) -> None:
+        for wk in self._works:
+            if wk is not None:
+                wk.wait()   # RCCL: the current stream waits for the communication stream; gloo: blocks the host
+        self._works = [None] * self.n_buckets
+
+    def _in_flight(self) -> bool:
+        return any(self._launched) and self._collective_needed()
+
+    def begin_backward(self) -> None:
+        """Called by an attached backward before it writes its first gradient.  A pass that starts while a bucket of
+        this step is already being reduced would accumulate local gradients into a partly summed buffer and write
+        beside a running collective: refused.  Otherwise every parameter counts as not ready again, so that the pass
+        that ends the step (the one outside ``no_sync``) announces all of them."""
+        if self._in_flight():
+            raise RuntimeError("FlatGradAllReducer: a backward pass started after this step's all-reduce had begun; "
+                               "run all but the last backward of a step under no_sync(), or call all_reduce() between them")
+        self._rearm()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context add to the buffer and start no collective."""
+        prev, self._defer = self._defer, True
+        try:
+            yield self
+        finally:
+            self._defer = prev
 
     def mark_ready(self, p: Tensor) -> None:
         """The gradient of ``p`` for this step is complete in its view (all kernels that write it are queued on the
@@ -114,15 +153,20 @@ class FlatGradAllReducer:
         i = self._index.get(id(p))
         if i is None or self._ready[i]:
             return
-        self._ready[i] = True
         b = self.bucket_of[i]
+        if self._launched[b] and self._collective_needed():
+            raise RuntimeError("FlatGradAllReducer.mark_ready: the bucket of this parameter is already being reduced "
+                               "(second backward of a step without no_sync()?)")
+        self._ready[i] = True
         self._left[b] -= 1
-        if self._left[b] == 0:
+        if self._left[b] == 0 and not self._defer:
             self._launch(b)
 
     def _launch(self, b: int) -> None:
         if self._launched[b]:
             return
+        if self._log_stale:
+            self.launch_log, self._log_stale = [], False
         self._launched[b] = True
         self.launch_log.append(b)
         if not self._collective_needed():
@@ -164,20 +208,21 @@ class FlatGradAllReducer:
 
     def all_reduce(self) -> None:
         """Average the gradients over the ranks (call after backward, before optimizer.step): starts the buckets
-        backward did not announce, waits for all of them, scales once."""
+        backward did not announce, waits for all of them, scales once, re-arms the buckets."""
         if self.gather:
             self.collect()
         for b in reversed(range(self.n_buckets)):   # backward fills the buffer from its end
             self._launch(b)
-        if not self._collective_needed():
-            return
-        for wk in self._works:
-            if wk is not None:
-                wk.wait()   # RCCL: the current stream waits for the communication stream; gloo: blocks the host
-        self._works = [None] * self.n_buckets
-        w = self.world_size
-        if w > 1:
-            self.flat.mul_(1.0 / w)
+        needed = self._collective_needed()
+        if needed:
+            self._wait_all()
+            w = self.world_size
+            if w > 1:
+                self.flat.mul_(1.0 / w)
+        # the step's reduction is complete: the next backward starts from armed buckets whether the caller zeroes the
+        # gradients through zero_grad(), optimizer.zero_grad(set_to_none=False) or flat.zero_()
+        self._rearm()
+        self._log_stale = True
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None, force_collective: bool = False) -> None:

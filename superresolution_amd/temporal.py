@@ -150,7 +150,9 @@ class GBuffersEncoder(nn.Module):
         last = self.conv_enhance[-1][0]
         if torch.is_grad_enabled():   # enhance_param is trained: the scale and the add stay visible to autograd
             y = A_.conv2d(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU)
-            return fmap + self.enhance_param.to(torch.bfloat16) * y, vmax
+            # the scale stays fp32 (inference passes float(enhance_param) as the epilogue's alpha and rounds the sum
+            # once): the product and the sum are formed in fp32, and enhance_param's gradient is an fp32 reduction
+            return (fmap.float() + self.enhance_param * y.float()).to(torch.bfloat16), vmax
         # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
         return F_.conv2d_auto(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU,
                               alpha=self._enhance_scale(), res=fmap), vmax

@@ -111,6 +111,8 @@ class _SuperSamplerFn(torch.autograd.Function):
         red = getattr(m, "_grad_reducer", None)   # data-parallel training: gradients go straight into its flat buffer
         if red is not None and (red.gather or any(red.grad_view(p) is None or p.grad is not red.grad_view(p) for p in m.parameters())):
             red = None
+        if red is not None:
+            red.begin_backward()
         f, up, gb, g, xs, ts, a, c0 = sv["f"], sv["up"], sv["gb"], sv["g"], sv["xs"], sv["ts"], sv["a"], sv["c0"]
 
         # final_conv (model.py:111-115,172)

@@ -75,3 +75,73 @@ def test_ops_refuse_cpu_tensors():
         F_.nchw_f32_to_nhwc_bf16(torch.zeros(1, 3, 4, 4))
     with pytest.raises(ValueError):
         F_.pixel_shuffle(torch.zeros(1, 4, 2, 2), 2)
+
+
+def _header_struct_fields(name: str):
+    """(type, field) pairs of `typedef struct { ... } name;` in include/srhip.h, comments stripped, arrays as 'x[3]'."""
+    text = open(os.path.join(ROOT, "include", "srhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct \{([^}]*)\}\s*" + name + r"\s*;", text).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(const void\*|void\*|const float\*|float\*|int|float)\s+(.*)", decl)
+        assert m, decl
+        for fld in m.group(2).split(","):
+            out.append((m.group(1), fld.strip()))
+    return out
+
+
+def _expected_layout(fields):
+    """Offsets and size the C compiler gives these fields on x86-64 / LP64 (natural alignment)."""
+    off, offs, align_max = 0, {}, 1
+    for typ, fld in fields:
+        size = 8 if "*" in typ else 4
+        cnt = 1
+        m = re.match(r"(\w+)\[(\d+)\]", fld)
+        if m:
+            fld, cnt = m.group(1), int(m.group(2))
+        off = (off + size - 1) // size * size
+        offs[fld] = off
+        off += size * cnt
+        align_max = max(align_max, size)
+    return offs, (off + align_max - 1) // align_max * align_max
+
+
+def test_every_args_struct_matches_the_header_field_for_field():
+    from superresolution_amd import _lib
+    for cname, cls in (("srhip_conv3x3_args", _lib.Conv3x3Args), ("srhip_conv3x3_pair_args", _lib.Conv3x3PairArgs),
+                       ("srhip_conv_gemm_args", _lib.ConvGemmArgs)):
+        fields = _header_struct_fields(cname)
+        offs, size = _expected_layout(fields)
+        names = [re.sub(r"\[\d+\]", "", f) for _, f in fields]
+        assert [f[0] for f in cls._fields_] == names, cname
+        assert ctypes.sizeof(cls) == size, cname
+        for fld, off in offs.items():
+            assert getattr(cls, fld).offset == off, (cname, fld)
+    assert ctypes.sizeof(_lib.Conv3x3Args) == 128 and ctypes.sizeof(_lib.Conv3x3PairArgs) == 88
+    assert ctypes.sizeof(_lib.ConvGemmArgs) == 136
+
+
+def integration_snippet() -> str:
+    """The ctypes example of INTEGRATION.md, verbatim."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(import ctypes, os, torch.*?)```", text, flags=re.S)
+    assert m, "INTEGRATION.md lost its ctypes example"
+    return m.group(1)
+
+
+def test_integration_stub_declares_the_same_struct():
+    from superresolution_amd._lib import Conv3x3Args
+    src = integration_snippet()
+    cls_src = src[src.index("class Conv3x3Args"):src.index("lib.srhip_conv3x3_packed_bytes.argtypes")]
+    ns = {"ctypes": ctypes}
+    exec(cls_src, ns)           # the class statement and its sizeof assertion only: no library call
+    doc = ns["Conv3x3Args"]
+    assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in Conv3x3Args._fields_]
+    assert ctypes.sizeof(doc) == ctypes.sizeof(Conv3x3Args)
+    # and the call in the example initialises every field
+    call = src[src.index("a = Conv3x3Args("):src.index("if lib.srhip_conv3x3_fwd")]
+    assert call.count(",") + 1 == len(Conv3x3Args._fields_)

@@ -2,6 +2,7 @@
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -188,3 +189,98 @@ def test_bucket_layout_covers_the_buffer_in_whole_parameters():
     # more buckets than parameters: never an empty bucket
     red = FlatGradAllReducer(params[:2], buckets=8)
     assert red.n_buckets <= 2 and all(hi > lo for lo, hi in red.bucket_range)
+
+
+def _rearm_worker(rank, world, port, q):
+    """Two ranks, three steps, gradients announced from 'inside backward' (mark_ready); the buffer is zeroed WITHOUT
+    FlatGradAllReducer.zero_grad (flat.zero_() / optimizer.zero_grad(set_to_none=False)).  Every step must still run
+    its collectives: the reduced buffer equals the mean of the two ranks' gradients each time."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from superresolution_amd.dp import FlatGradAllReducer
+        torch.manual_seed(5)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in ((7, 3), (5,), (4, 4, 3), (9,))]
+        red = FlatGradAllReducer(params, buckets=2)
+        opt = torch.optim.SGD(params, lr=0.0)
+        out = []
+        for step in range(3):
+            if step == 1:
+                red.flat.zero_()
+            elif step == 2:
+                opt.zero_grad(set_to_none=False)
+            g = torch.Generator().manual_seed(1000 * step + rank)
+            grads = [torch.randn(p.shape, generator=g) for p in params]
+            red.begin_backward()
+            for p, gr in reversed(list(zip(params, grads))):
+                red.grad_view(p).add_(gr)
+                red.mark_ready(p)
+            in_backward = list(red.launch_log)
+            red.all_reduce()
+            red.check_views()
+            local = torch.cat([gr.reshape(-1) for gr in grads])
+            out.append((red.flat.clone().numpy(), local.numpy(), in_backward))
+        # two backward passes in one step: the first under no_sync() starts nothing, the second reduces the sum
+        red.zero_grad()
+        ga = [torch.full(p.shape, float(rank + 1)) for p in params]
+        gb = [torch.full(p.shape, 10.0 * (rank + 1)) for p in params]
+        with red.no_sync():
+            red.begin_backward()
+            for p, gr in reversed(list(zip(params, ga))):
+                red.grad_view(p).add_(gr)
+                red.mark_ready(p)
+            deferred = list(red.launch_log)
+        red.begin_backward()
+        for p, gr in reversed(list(zip(params, gb))):
+            red.grad_view(p).add_(gr)
+            red.mark_ready(p)
+        second = list(red.launch_log)
+        # a third backward now would race the collectives already started: refused
+        try:
+            red.begin_backward()
+            refused = False
+        except RuntimeError:
+            refused = True
+        red.all_reduce()
+        q.put((rank, out, deferred, second, refused, red.flat.clone().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_buckets_rearm_without_zero_grad_and_accumulation_under_no_sync():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rearm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, out0, def0, sec0, ref0, acc0), (_, out1, def1, sec1, ref1, acc1) = res
+    for step in range(3):
+        red0, loc0, log0 = out0[step]
+        red1, loc1, log1 = out1[step]
+        assert log0 == [1, 0] and log1 == [1, 0], f"step {step}: the buckets did not start from inside backward"
+        assert (red0 == red1).all(), f"step {step}: replicas hold different reduced gradients"
+        assert np.allclose(red0, 0.5 * (loc0 + loc1), rtol=1e-6, atol=1e-7), f"step {step}: no collective ran"
+    assert def0 == [] and def1 == [], "no_sync() must not start a collective"
+    assert sec0 == [1, 0] and sec1 == [1, 0]
+    assert ref0 and ref1, "a backward pass beside running collectives must be refused"
+    assert (acc0 == acc1).all() and np.allclose(acc0, 0.5 * (11.0 + 22.0))
+
+
+def test_single_rank_second_backward_is_not_refused():
+    """Without a collective nothing is in flight: two announced backward passes in a row simply accumulate."""
+    from superresolution_amd.dp import FlatGradAllReducer
+    params = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))]
+    red = FlatGradAllReducer(params, buckets=2)
+    for _ in range(2):
+        red.begin_backward()
+        for p in reversed(params):
+            red.grad_view(p).add_(1.0)
+            red.mark_ready(p)
+    red.all_reduce()
+    assert torch.equal(red.flat, torch.full((5,), 2.0))
