@@ -26,6 +26,7 @@
 //     and all per-row issue work (LDS-DMA pieces, residual loads) are micro-steps interleaved with
 //     the MFMAs of the NEXT row, so they hide in the matrix pipe's shadow.
 #include <atomic>
+#include <cstdlib>
 
 #include "conv_mfma_util.h"
 #include "srhip_common.h"
@@ -636,6 +637,320 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// concat(32 ch, 64 ch) -> 64 with the REDUCTION split over the two waves of a pixel group (core/models/model.py:169-170).
+//
+// Cfg<6, 2, 2> above splits that layer over OUTPUT channels: a wave holds one 32-channel tile for all 96 input channels,
+// so every pixel fragment it reads from LDS feeds a single MFMA -- four waves then ask the LDS for 128 bytes per clock
+// at full matrix rate, its whole bandwidth, and the layer ran LDS-bound.  Here a wave holds BOTH output tiles for HALF
+// of the input channels (k-chunks {A0, A1, B0} or {B1, B2, B3}: 216 registers of weights either way), every fragment
+// feeds two MFMAs, and the two partial accumulators meet in the fp32 staging area the epilogue crosses anyway: each wave
+// stages its 32 x 64 partial, and after the next row's barrier finishes HALF of the pixel group's store groups from the
+// sum of both partials.  Staging is double buffered by row parity (the partner may still be reading row i - 1 when
+// this wave stages row i).  ReLU / bias / alpha epilogue, bf16 NHWC output, no residual and no sign-bit forms: what
+// the network's two concat layers need.
+// ------------------------------------------------------------------------------------------------------------------
+struct KsCfg {
+    using L = Cfg<6, 2, 2, false, 0, 0>;                // LDS row image, LDS-DMA pieces and strip width of the concat layer
+    static constexpr int KCW = 3, NCT = 2, MPT = KCW * NCT;
+    static constexpr int NWAVES = 4, TW = L::TW;
+    static constexpr int LA = L::LA, RING = L::RING, SLOT_BYTES = L::SLOT_BYTES, RING_BYTES = L::RING_BYTES;
+    static constexpr int NPIECE = L::NPIECE, MAXP = L::MAXP;
+    static constexpr int PXS = 256;                     // staged bytes per pixel (64 fp32)
+    static constexpr int STAGE_BYTES = 32 * PXS;        // per wave and row parity
+    static constexpr int STAGE_OFF = RING_BYTES;        // [parity][wave]
+    static constexpr int DUMMY_OFF = STAGE_OFF + 2 * NWAVES * STAGE_BYTES;
+    static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
+    // vector-memory operations of one row and wave, in issue order: LDS-DMA pieces in taps 0..MAXP-1, the two stores in
+    // taps 4 and 8
+    static constexpr int VM_ROW = MAXP + 2;
+    static constexpr int WAIT_STEADY = (VM_ROW - MAXP) + (LA - 3) * VM_ROW;
+    static constexpr int WAIT_EARLY = (LA - 4) * MAXP + VM_ROW < (LA - 3) * VM_ROW ? (LA - 4) * MAXP + VM_ROW : (LA - 3) * VM_ROW;
+    static_assert(MAXP <= 4 && LA == 5 && WAIT_STEADY <= 63, "stores sit in taps 4 and 8 behind the row's last DMA piece");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+__global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(const ConvParams p)
+{
+    using C = KsCfg;
+    using L = KsCfg::L;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave & 1;          // which half of the reduction this wave owns
+    const int pg = wave >> 1;         // which 32-pixel group of the row
+    const int hl = lane >> 5, pl = lane & 31;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    bf16x8 wreg[9][C::KCW][C::NCT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int j = 0; j < C::KCW; ++j)
+#pragma unroll
+            for (int ct = 0; ct < C::NCT; ++ct) wreg[t][j][ct] = p.wpack[((t * 6 + 3 * kh + j) * 2 + ct) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<0, 9 * C::KCW * C::NCT>([&](auto f_c) {   // the loads land before the row loop, not between its MFMAs
+        SRHIP_CAPTURE(wreg);
+        constexpr int f = decltype(f_c)::value;
+        asm volatile("" : "+a"(wreg[f / (C::KCW * C::NCT)][(f / C::NCT) % C::KCW][f % C::NCT]));
+    });
+
+    // store-time lane roles: lane = (pixel st_q of a group of 8 pixels, 8-channel chunk st_c); this wave finishes store
+    // groups 2 kh and 2 kh + 1 of its pixel group from both waves' partials
+    const int st_q = lane >> 3, st_c = lane & 7;
+    const unsigned stage0 = lds_base + (unsigned)C::STAGE_OFF;
+    // own staging area of parity 0 / the pair's two areas (k half 0 first: the sum is formed in one order everywhere)
+    const unsigned wst = stage0 + (unsigned)(wave * C::STAGE_BYTES) + (unsigned)(pl * C::PXS) + (unsigned)(((hl ^ (pl & 15)) & 15) << 4);
+    unsigned rda[2], rdb[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int q = (2 * kh + g) * 8 + st_q;
+        const unsigned off = (unsigned)(q * C::PXS) + (unsigned)((((2 * st_c) ^ (q & 15)) & 15) << 4);
+        rda[g] = stage0 + (unsigned)((2 * pg) * C::STAGE_BYTES) + off;
+        rdb[g] = stage0 + (unsigned)((2 * pg + 1) * C::STAGE_BYTES) + off;
+    }
+    float breg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int co = st_c * 8 + r;
+        breg[r] = ((p.bias != nullptr && co < p.cout) ? p.bias[co] : 0.0f) * p.alpha;
+    }
+    // fragment j of tap column kx: k-chunk 3 kh + j = (sub-image, chunk pair) of LDS pixel 32 pg + pl + kx
+    unsigned rdk[3][C::KCW];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = 32 * pg + pl + kx;
+#pragma unroll
+        for (int j = 0; j < C::KCW; ++j) {
+            const int c = 3 * kh + j;
+            const int sub = c >= 2 ? 1 : 0, kcl = c - 2 * sub;
+            const int cpp = sub ? L::cpp(1) : L::cpp(0), lc = sub ? L::lcpp(1) : L::lcpp(0);
+            const int f = (px >> (4 - lc)) & (cpp - 1);
+            const unsigned off = (unsigned)((sub ? L::sub_off(1) : 0) + px * cpp * 16 + ((hl ^ f) << 4));
+            rdk[kx][j] = lds_base + (off ^ (unsigned)(kcl << 5));
+        }
+    }
+
+    const int H = p.h, W = p.w;
+    const int csrc0 = p.ca_stride, csrc1 = p.cb;
+    bf16x8 bq[2][C::KCW];
+    f32x16 acc[C::NCT];
+    f32x4 ea[2][2], eb[2][2];   // [store group of this wave][lo / hi]: k half 0's and k half 1's partial
+    float ev[8];
+
+    const int item_stride = p.main_items == p.total_items ? (int)gridDim.x
+                                                          : ((int)blockIdx.x < p.main_items ? p.total_items : p.tail_stride);
+    for (int item = blockIdx.x; item < p.total_items; item += item_stride) {
+        int strip, n, y0, y1;
+        if (item < p.main_items) {
+            strip = item % p.nstrips;
+            const int tseg = item / p.nstrips;
+            n = tseg / p.nsegs;
+            y0 = (tseg % p.nsegs) * p.seg_h;
+            y1 = min(y0 + p.seg_h, p.main_h);
+        } else {
+            const int k = item - p.main_items;
+            strip = k % p.nstrips;
+            n = k / p.nstrips;
+            y0 = p.main_h;
+            y1 = H;
+        }
+        const int x0 = strip * C::TW;
+        const int nout = y1 - y0;
+        const int nin = nout + 2;
+
+        const unsigned img_a = (unsigned)(H * W) * (unsigned)csrc0 * 2u;
+        const unsigned img_b = (unsigned)(H * W) * (unsigned)csrc1 * 2u;
+        const __amdgpu_buffer_rsrc_t rsrc_a =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.src_a + (long long)n * img_a), 0, (int)img_a, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_b =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(p.src_b + (long long)n * img_b), 0, (int)img_b, 0x00020000);
+        const unsigned img_out = (unsigned)(H * W) * (unsigned)p.cout_stride * 2u;
+        const i32x4 dst_srd = make_srd(p.dst + (long long)n * img_out, img_out);
+        const unsigned out_pitch = (unsigned)W * (unsigned)p.cout_stride * 2u;
+
+        unsigned poff[C::MAXP];
+        bool psub1[C::MAXP];
+#pragma unroll
+        for (int m = 0; m < C::MAXP; ++m) {
+            const int q = wave + m * C::NWAVES;
+            const bool s1 = q >= L::piece_base(1);
+            const int j = (q - (s1 ? L::piece_base(1) : 0)) * 64 + lane;
+            const int lc = s1 ? L::lcpp(1) : L::lcpp(0);
+            const int px = j >> lc;
+            const int slot = j & ((1 << lc) - 1);
+            const int c = slot ^ ((px >> (4 - lc)) & ((1 << lc) - 1));
+            const int x = x0 - 1 + px;
+            const bool ok = (x >= 0) && (x < W) && (px < C::TW + 2);
+            poff[m] = ok ? (unsigned)((x * (s1 ? csrc1 : csrc0) + c * 8) * 2) : kOobOffset;
+            psub1[m] = s1;
+        }
+        unsigned vox[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int xq = x0 + 32 * pg + (2 * kh + g) * 8 + st_q;
+            vox[g] = (xq < W && st_c * 8 < p.cout_w) ? (unsigned)((xq * p.cout_stride + st_c * 8) * 2) : kOobOffset;
+        }
+
+        int ring_pos = 0;
+        auto issue_piece = [&](auto m_c, const unsigned soff0, const unsigned soff1, const unsigned slot_off) {
+            constexpr int m = decltype(m_c)::value;
+            const int q = wave + m * C::NWAVES;
+            const bool mine = (m < C::MAXP - 1) || (q < C::NPIECE);
+            const unsigned off = mine ? slot_off + (unsigned)q * 1024u : (unsigned)C::DUMMY_OFF;
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + off);
+            if (psub1[m]) lds_dma_b128(rsrc_b, dst, poff[m], soff1);
+            else lds_dma_b128(rsrc_a, dst, poff[m], soff0);
+        };
+        auto row_soff = [&](const int r, unsigned& soff0, unsigned& soff1) {
+            const int y = y0 - 1 + r;
+            const bool yin = (y >= 0) & (y < H) & (r < nin);
+            const unsigned pix = (unsigned)(y * W);
+            soff0 = yin ? pix * (unsigned)(csrc0 * 2) : kOobOffset;
+            soff1 = yin ? pix * (unsigned)(csrc1 * 2) : kOobOffset;
+        };
+        // epilogue of store group g (0 / 1 of this wave) of the row staged with parity SP
+        auto epi_read = [&](auto g_c, const unsigned par_off) {
+            constexpr int g = decltype(g_c)::value;
+            ea[g][0] = lds_read_f32x4(rda[g] + par_off);
+            ea[g][1] = lds_read_f32x4((rda[g] + par_off) ^ 16u);
+            eb[g][0] = lds_read_f32x4(rdb[g] + par_off);
+            eb[g][1] = lds_read_f32x4((rdb[g] + par_off) ^ 16u);
+        };
+        auto epi_fence = [&](auto g_c) {
+            SRHIP_CAPTURE(ea); SRHIP_CAPTURE(eb);
+            constexpr int g = decltype(g_c)::value;
+            SRHIP_LOAD_FENCE(ea[g][0]); SRHIP_LOAD_FENCE(ea[g][1]); SRHIP_LOAD_FENCE(eb[g][0]); SRHIP_LOAD_FENCE(eb[g][1]);
+        };
+        auto epi_elem = [&](auto g_c, auto e_c) {
+            constexpr int g = decltype(g_c)::value;
+            constexpr int e = decltype(e_c)::value;
+            const float x = ea[g][e >> 2][e & 3] + eb[g][e >> 2][e & 3];
+            const float t = fmaf(x, p.alpha, breg[e]);
+            ev[e] = fmaxf(t, t * p.slope);
+        };
+        auto epi_store = [&](auto g_c, const unsigned store_soff) {
+            constexpr int g = decltype(g_c)::value;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
+            buffer_store_b128_guarded(o, dst_srd, vox[g], store_soff);
+        };
+
+        auto row_body = [&](auto par_c, const int i) {
+            constexpr int PAR = decltype(par_c)::value;
+            if (i == 0) vm_wait<0>();
+            else if (i < C::LA - 2) vm_wait<C::WAIT_EARLY>();
+            else vm_wait<C::WAIT_STEADY>();
+            lds_wait<0>();   // this wave's staged partial of row i-1 is complete before its partner is told so
+            __builtin_amdgcn_s_barrier();
+
+            const int y = y0 + i;
+            unsigned dma_s0, dma_s1;
+            row_soff(i + C::LA, dma_s0, dma_s1);
+            const unsigned dma_slot = (unsigned)((ring_pos == 0 ? C::RING - 1 : ring_pos - 1) * C::SLOT_BYTES);
+            const unsigned st_soff = i > 0 ? (unsigned)(y - 1) * out_pitch : kOobOffset;   // stores of row i-1
+            const unsigned prev_stage = (unsigned)((PAR ^ 1) * C::NWAVES * C::STAGE_BYTES);  // where row i-1 was staged
+            unsigned rowa[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sl = ring_pos + ky;
+                rowa[ky] = (unsigned)((sl >= C::RING ? sl - C::RING : sl) * C::SLOT_BYTES);
+            }
+            ring_pos = (ring_pos + 1 == C::RING) ? 0 : ring_pos + 1;
+
+            if constexpr (PAR == 0) {
+                if (i == 0) {
+                    static_for<0, C::KCW>([&](auto j_c) {
+                        constexpr int j = decltype(j_c)::value;
+                        bq[0][j] = lds_read_b128(rowa[0] + rdk[0][j]);
+                    });
+                    lds_wait<0>();
+                    static_for<0, C::KCW>([&](auto j_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(j_c)::value]); });
+                }
+            }
+
+            // tap t of row i: 6 MFMAs; gap 0 carries the staging reads of a store group of row i-1 (taps 0 and 4),
+            // gaps 1..3 the three fragments of the next tap; between them the previous row's epilogue arithmetic
+            // (group 0 in taps 1..3, stored in tap 4; group 1 in taps 5..7, stored in tap 8) and the LDS-DMA pieces of
+            // row i+LA (taps 0..MAXP-1)
+            static_for<0, 9>([&](auto t_c) {
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(ea); SRHIP_CAPTURE(eb); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(wreg);
+                constexpr int t = decltype(t_c)::value;
+                constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
+                constexpr int tn = (t + 1) % 9;
+                constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                lds_wait<0>();
+                if constexpr (t == 1) epi_fence(IntC<0>{});
+                if constexpr (t == 5) epi_fence(IntC<1>{});
+                static_for<0, C::KCW>([&](auto j_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(j_c)::value]); });
+                static_for<0, C::MPT>([&](auto m_c) {
+                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(ea); SRHIP_CAPTURE(eb); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(wreg);
+                    constexpr int ml = decltype(m_c)::value;
+                    constexpr int j = ml / C::NCT, ct = ml % C::NCT;
+                    mfma_pinned<true, (t == 0 && j == 0), ct>(acc[ct], wreg[t][j][ct], bq[cur][j]);
+                    if constexpr (ml == 0 && t == 0) epi_read(IntC<0 * ml>{}, prev_stage);
+                    if constexpr (ml == 0 && t == 4) epi_read(IntC<1 + 0 * ml>{}, prev_stage);
+                    if constexpr (ml >= 1 && ml <= C::KCW) {
+                        constexpr int jr = ml - 1;
+                        bq[nxt][jr] = lds_read_b128(rowa[kyn] + rdk[tn % 3][jr]);
+                    }
+                    // epilogue arithmetic of row i-1: taps 1..3 / 5..7 take elements {0,1,2}, {3,4,5}, {6,7} in gaps 3..5
+                    if constexpr ((t >= 1 && t <= 3) || (t >= 5 && t <= 7)) {
+                        constexpr int G = t >= 5 ? 1 : 0;
+                        constexpr int e = 3 * ((t - 1) & 3) + (ml - 3);
+                        if constexpr (ml >= 3 && e < 8 && e < 3 * ((t - 1) & 3) + 3) epi_elem(IntC<G + 0 * ml>{}, IntC<e>{});
+                    }
+                    if constexpr (t == 4 && ml == 4) epi_store(IntC<0 * ml>{}, st_soff);
+                    if constexpr (t == 8 && ml == 4) epi_store(IntC<1 + 0 * ml>{}, st_soff);
+                    if constexpr (t < C::MAXP && ml == 5) issue_piece(IntC<t + 0 * ml>{}, dma_s0, dma_s1, dma_slot);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]), "+" SRHIP_ACC_REG1(acc[1]));
+            constexpr unsigned own_stage = (unsigned)(PAR * C::NWAVES * C::STAGE_BYTES);
+            static_for<0, 4 * C::NCT>([&](auto s_c) {
+                constexpr int S = decltype(s_c)::value;
+                constexpr int ct = S / 4, g = S % 4;
+                lds_write_acc_quad<ct, g>((wst + own_stage) ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);
+            });
+            lds_wait<4 * C::NCT>();   // tap 8's fragments of the next row's tap 0 (older than the staging writes)
+            static_for<0, C::KCW>([&](auto j_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(j_c)::value]); });
+        };
+
+        __builtin_amdgcn_s_barrier();  // every wave is done with the previous item's rows and staged partials
+#pragma unroll 1
+        for (int r = 0; r < C::LA; ++r) {
+            unsigned s0, s1;
+            row_soff(r, s0, s1);
+            static_for<0, C::MAXP>([&](auto m_c) { issue_piece(m_c, s0, s1, (unsigned)(r * C::SLOT_BYTES)); });
+        }
+        ring_pos = 0;
+#pragma unroll 1
+        for (int i = 0; i < nout; i += 2) {
+            row_body(IntC<0>{}, i);
+            if (i + 1 < nout) row_body(IntC<1>{}, i + 1);
+        }
+        // drain: the last row's partials meet
+        lds_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        {
+            const unsigned st_soff = (unsigned)(y1 - 1) * out_pitch;
+            const unsigned last_stage = (unsigned)(((nout - 1) & 1) * C::NWAVES * C::STAGE_BYTES);
+            static_for<0, 2>([&](auto g_c) {
+                epi_read(g_c, last_stage);
+                lds_wait<0>();
+                epi_fence(g_c);
+                static_for<0, 8>([&](auto e_c) { epi_elem(g_c, e_c); });
+                epi_store(g_c, st_soff);
+            });
+        }
+    }
+}
+
 // fp32 OIHW master weights -> bf16 MFMA fragment order [tap][kc][cout tile][lane][8].
 __global__ void pack_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int w_o,
                                     int w_i, int cout, int cout_off, int cin_a_real, int ca_pad,
@@ -670,8 +985,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, unsigned short*
     out[idx] = f32_to_bf16_bits(v);
 }
 
-template <class C>
-int launch_conv(ConvParams p, hipStream_t stream)
+template <class C, class Kernel>
+int launch_conv_with(ConvParams p, hipStream_t stream, Kernel kernel)
 {
     // per device, immutable after the first call on that device for this instantiation
     static std::atomic<int> blocks_per_cu_dev[kSrhipMaxDevices];
@@ -679,14 +994,14 @@ int launch_conv(ConvParams p, hipStream_t stream)
     int blocks_per_cu = blocks_per_cu_dev[dev].load(std::memory_order_acquire);
     if (blocks_per_cu == 0) {
         if (C::LDS_BYTES > 48 * 1024) {
-            if (hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     C::LDS_BYTES) != hipSuccess) {
                 srhip_set_error("conv3x3: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);
                 return SRHIP_ERR_LAUNCH;
             }
         }
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_kernel<C>, C::NWAVES * 64, C::LDS_BYTES) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, C::NWAVES * 64, C::LDS_BYTES) !=
                 hipSuccess || nb < 1)
             nb = 1;
         blocks_per_cu = nb > 2 ? 2 : nb;
@@ -744,8 +1059,13 @@ int launch_conv(ConvParams p, hipStream_t stream)
     SRHIP_REQUIRE(total < (1ll << 30), "conv3x3: too many work items");
     p.total_items = (int)total;
     const int grid = p.main_items != p.total_items ? slots : (int)(total < slots ? total : slots);
-    hipLaunchKernelGGL(conv3x3_kernel<C>, dim3(grid), dim3(C::NWAVES * 64), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(C::NWAVES * 64), C::LDS_BYTES, stream, p);
     return srhip_check_launch("conv3x3_kernel");
+}
+template <class C>
+int launch_conv(ConvParams p, hipStream_t stream)
+{
+    return launch_conv_with<C>(p, stream, conv3x3_kernel<C>);
 }
 
 }  // namespace
@@ -852,6 +1172,12 @@ SRHIP_API int srhip_conv3x3_fwd(const srhip_conv3x3_args* a, void* stream)
         }
         srhip_set_error("conv3x3: sign-bit form %d is not built for cin=%d with%s residual", a->aux_mode, a->ca, a->res ? "" : "out");
         return SRHIP_ERR_INVALID;
+    }
+    // concat(32, 64) -> 64 without a residual: the reduction-split kernel (SRHIP_NO_KSPLIT=1 keeps the output-channel split
+    // for A/B timing)
+    if (kc == 6 && ct == 2 && a->res == nullptr && !a->dst_nchw_f32) {
+        static const bool ksplit = []() { const char* e = getenv("SRHIP_NO_KSPLIT"); return !(e && e[0] == '1'); }();
+        if (ksplit) return launch_conv_with<KsCfg>(p, s, conv3x3_ksplit_kernel);
     }
 #define SRHIP_CONV_CASE(KC, CT, CSPLIT)                                                                 \
     if (kc == KC && ct == CT) {                                                                         \

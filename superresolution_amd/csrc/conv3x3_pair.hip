@@ -22,6 +22,8 @@
 // Every vector-memory operation and every LDS read is asm with a COUNTED wait, as in the single-layer kernel; the same
 // fence discipline applies (tools/isa_lint.py checks it).
 #include <atomic>
+#include <cstdlib>
+#include <type_traits>
 
 #include "conv_mfma_util.h"
 #include "srhip_common.h"
@@ -48,6 +50,7 @@ struct PairParams {
     // end of one strip and the start of the next; every maximal run inside one strip is a work item.
     int range_rows;
     int cout2;   // head form: output channels (1..32) of the second layer, written as fp32 NCHW planes
+    int two;     // output columns per strip (the geometry's TWO)
 };
 
 struct PairCfg {
@@ -59,6 +62,7 @@ struct PairCfg {
     static constexpr int PITCH = 72;                   // pixels per LDS row image (whole 1-KiB pieces)
     static constexpr int SLOT_BYTES = PITCH * CH * 2;  // 9216
     static constexpr int NPIECE = SLOT_BYTES / 1024;   // 9 LDS-DMA pieces per x row
+    static constexpr int NW1 = 2;                      // first-layer waves (32 columns of `mid` each)
     static constexpr int MAXP = 5;                     // pieces per first-layer wave per row (wave w: w, w+2, ..., w+8)
     static constexpr int LA = 5;                       // x rows fetched ahead of the row being computed
     static constexpr int RING = 8;                     // x row slots: rows s-2 (the second layer's residual) .. s+LA in step s
@@ -75,6 +79,39 @@ struct PairCfg {
     static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
     static constexpr int NFA1 = 256 / 4;               // first layer: accumulators in VGPRs, 64 fragments in AGPRs
     static constexpr int NFA2 = (256 - 16 * NCT) / 4;  // second layer: accumulators a[0:31], 56 fragments in AGPRs
+};
+
+// Geometry of the HEAD3 form (the network's last two layers, 64 -> 64 -> cout2 <= 8): THREE first-layer waves and one wave
+// for the narrow second layer.  In the two-plus-two split above a narrow second layer leaves its two waves idle half of
+// the time and the launch costs what the first layer costs on two of the four SIMDs.  Here the second layer is
+// reformulated so that one wave carries it for 96 columns: the matrix instruction's 32 output rows hold (kernel row dy,
+// output channel co) pairs, so ONE pass over a `mid` row with the three column shifts (3 x 4 MFMAs per 32 pixels instead
+// of 9 x 4) yields that row's contribution to the three output rows it touches, and the sum over dy is three vector
+// adds per output in registers.  A strip is 92 output columns (94 `mid` columns from 96 columns of x: twelve 1-KiB
+// pieces per row, four per first-layer wave); the x ring needs no residual rows, so six slots of 12 KiB keep every
+// slot inside the 16-bit offset field of the LDS instructions.
+struct HeadCfg {
+    static constexpr int CH = 64;
+    static constexpr int KC = 4, NCT = 2;
+    static constexpr int MPT = KC * NCT;
+    static constexpr int NW1 = 3;                      // first-layer waves
+    static constexpr int TWO = 92;                     // output columns per strip
+    static constexpr int XPX = 96;                     // x columns per row held in LDS (valid mid columns: 94)
+    static constexpr int PITCH = 96;
+    static constexpr int SLOT_BYTES = PITCH * CH * 2;  // 12288
+    static constexpr int NPIECE = SLOT_BYTES / 1024;   // 12
+    static constexpr int MAXP = 4;                     // wave w: pieces w, w+3, w+6, w+9
+    static constexpr int LA = 5;
+    static constexpr int RING = 6;                     // x rows s .. s+LA in step s
+    static constexpr int NY = 2;                       // mid rows: s-1 being written, s-2 being read by the head wave
+    static constexpr int LAG = 4;                      // steps per item beyond its output rows
+    static constexpr int XRING_BYTES = RING * SLOT_BYTES;
+    static constexpr int YRING_OFF = XRING_BYTES;
+    static constexpr int YRING_BYTES = NY * SLOT_BYTES;
+    static constexpr int DUMMY_OFF = YRING_OFF + YRING_BYTES;   // also absorbs the head wave's reads of mid pixels 96, 97
+    static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
+    static constexpr int NFA1 = 256 / 4;
+    static_assert(NPIECE == NW1 * MAXP && (RING - 1) * SLOT_BYTES < 65536, "piece ownership / LDS offset field");
 };
 
 // MFMA of the first layer: accumulator in VGPRs (the epilogue's vector ALU reads it directly); the first MFMA of a
@@ -159,13 +196,13 @@ __device__ __forceinline__ PairItem pair_decode_item(const PairParams& p, int it
         const int tseg = item / p.nstrips;
         const int seg = tseg % p.nsegs;
         it.n = tseg / p.nsegs;
-        it.x0 = strip * PairCfg::TWO;
+        it.x0 = strip * p.two;
         it.y0 = seg * p.seg_h;
         it.nout = min(it.y0 + p.seg_h, p.main_h) - it.y0;
     } else {
         const int k = item - p.main_items;
         it.n = k / p.nstrips;
-        it.x0 = (k % p.nstrips) * PairCfg::TWO;
+        it.x0 = (k % p.nstrips) * p.two;
         it.y0 = p.main_h;
         it.nout = p.h - p.main_h;
     }
@@ -192,7 +229,7 @@ __device__ __forceinline__ bool pair_iter_next(const PairParams& p, PairIter& i,
         if (i.r >= i.r1) return false;
         const int col = i.r / p.h, y = i.r - col * p.h;
         it.n = col / p.nstrips;
-        it.x0 = (col - it.n * p.nstrips) * PairCfg::TWO;
+        it.x0 = (col - it.n * p.nstrips) * p.two;
         it.y0 = y;
         it.nout = min(p.h - y, i.r1 - i.r);
         i.r += it.nout;
@@ -208,11 +245,10 @@ __device__ __forceinline__ bool pair_iter_next(const PairParams& p, PairIter& i,
 // Waves 0-1: first layer.  Step s computes mid row s (image row y0 - 1 + s) for the 32 columns x0 - 1 + 32 pg + pl from
 // x rows s .. s+2 of the ring; the row's epilogue (accumulators -> bf16 -> LDS) runs between the MFMAs of step s + 1.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool STORE_MID>
+template <bool STORE_MID, class P>
 __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
                                                  const int lane)
 {
-    using P = PairCfg;
     const int hl = lane >> 5, pl = lane & 31;
     constexpr bool IMM = !STORE_MID;               // compile-time ring slots (see `step`)
     constexpr int UNR = IMM ? P::RING : 2;         // copies of the row loop's body
@@ -297,7 +333,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
         unsigned poff[P::MAXP];
 #pragma unroll
         for (int m = 0; m < P::MAXP; ++m) {
-            const int piece = pg + 2 * m;
+            const int piece = pg + P::NW1 * m;
             const int j = piece * 64 + lane;
             const int px = j >> 3;
             const int c = (j & 7) ^ ((px >> 1) & 7);
@@ -317,7 +353,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
 
         auto issue_piece = [&](auto m_c, const unsigned soff, const unsigned slot_off) {
             constexpr int m = decltype(m_c)::value;
-            const int piece = pg + 2 * m;
+            const int piece = pg + P::NW1 * m;
             const bool mine = (m < P::MAXP - 1) || (piece < P::NPIECE);
             const unsigned off = mine ? slot_off + (unsigned)piece * 1024u : (unsigned)P::DUMMY_OFF;
             lds_dma_b128(rsrc_x, (__attribute__((address_space(3))) void*)(smem + off), poff[m], soff);
@@ -353,12 +389,13 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             const int yr = s - 1;
             const int yimg = y0 - 1 + yr;
             // offset of slot (s - 1) mod NY: in the instruction (IMM) or added to the address registers
-            constexpr int YSLOT = IMM ? ((Q + P::NY - 1) & (P::NY - 1)) * P::SLOT_BYTES : 0;
-            const unsigned yslot_dyn = IMM ? 0u : (unsigned)((yr & (P::NY - 1)) * P::SLOT_BYTES);
+            static_assert(P::RING % P::NY == 0 && P::RING % 2 == 0, "the step's ring phase fixes the mid slot and the row parity");
+            constexpr int YSLOT = IMM ? ((Q + P::NY - 1) % P::NY) * P::SLOT_BYTES : 0;
+            const unsigned yslot_dyn = IMM ? 0u : (unsigned)(((s + P::NY - 1) % P::NY) * P::SLOT_BYTES);
             const unsigned wys = wy + yslot_dyn;
             unsigned rowx[3];   // !IMM: x-ring slot offsets of rows s .. s+2
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) rowx[ky] = IMM ? 0u : (unsigned)(((s + ky) & (P::RING - 1)) * P::SLOT_BYTES);
+            for (int ky = 0; ky < 3; ++ky) rowx[ky] = IMM ? 0u : (unsigned)(((s + ky) % P::RING) * P::SLOT_BYTES);
             const unsigned ymask = (s >= 1 && yimg >= 0 && yimg < H) ? colmask : 0u;
             // mid row s-2 (read back at the end of step s-1) goes to HBM if it is one of the segment's own rows
             const int mr = s - 2;
@@ -386,7 +423,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             }
 
             const unsigned dma_soff = row_soff(s + P::LA);
-            const unsigned dma_slot = (unsigned)(((s + P::LA) & (P::RING - 1)) * P::SLOT_BYTES);
+            const unsigned dma_slot = (unsigned)(((s + P::LA) % P::RING) * P::SLOT_BYTES);
 
             if constexpr (Q == 0) {
                 if (s == 0) {  // first row of the item: nobody fetched its tap 0 yet
@@ -421,7 +458,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                     // gaps 1..KC: pixel fragments of the next tap (tap 8: tap 0 of the next row, whose x rows are resident)
                     if constexpr (ml >= 1 && ml <= P::KC) {
                         constexpr int kr = ml - 1;
-                        bq[nxt][kr] = lds_read_b128_sel<IMM, ((Q + kyn) & (P::RING - 1)) * P::SLOT_BYTES>(rowx[kyn], rd[tn % 3][kr]);
+                        bq[nxt][kr] = lds_read_b128_sel<IMM, ((Q + kyn) % P::RING) * P::SLOT_BYTES>(rowx[kyn], rd[tn % 3][kr]);
                     }
                     // taps 0..7: quad t of the previous row's accumulators -> mid ring
                     if constexpr (t < 8) {
@@ -828,7 +865,141 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
     }
 }
 
-template <bool STORE_MID, int ACT2, bool HEAD = false>
+// MFMA with everything in VGPRs (the head wave has registers to spare); FIRST starts a chain from C = 0.
+template <bool FIRST>
+__device__ __forceinline__ void mfma_vv(f32x16& acc, const bf16x8& w, const bf16x8& b)
+{
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));
+}
+
+// HEAD3: the narrow second layer (64 -> cout2 <= 8, fp32 NCHW out, no residual) on ONE wave for the strip's three pixel
+// groups.  Step s handles mid row r = s - 2 (complete since the barrier of this step): for each 32-pixel group
+//     R[8 dy + co][px] = sum over dx, k of W2[co][k][dy][dx] * mid[r][px + dx][k]           (3 x 4 MFMAs)
+// and, with out[o] = R_o[dy 0] + R_{o+1}[dy 1] + R_{o+2}[dy 2], two running sums per group and channel:
+//     out[r-2] = S1 + R[dy 2] (+ bias, activation, alpha -> stored),   S1 <- S0 + R[dy 1],   S0 <- R[dy 0].
+// Rows of `mid` outside the image are zeros in the ring, so the vertical padding needs nothing here.  Accumulator
+// register 4 dy + e of lane (pl, hl) is channel 4 hl + e of pixel pl.
+template <int ACT2, class P>
+__device__ __forceinline__ void pair_head3_layer(const PairParams& p, char* smem, const unsigned lds_base, const int lane)
+{
+    constexpr int NG = P::NW1;
+    const int hl = lane >> 5, pl = lane & 31;
+    // weights from the standard 64 -> cout2 pack ([tap][kc][lane][8], lane = (k half, output channel)): this lane is
+    // matrix row 8 dy + co
+    bf16x8 wh[3][P::KC];
+    {
+        const int m = lane & 31, dyw = m >> 3, cow = m & 7;
+        const bool wok = dyw < 3 && cow < p.cout2;
+        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int kc = 0; kc < P::KC; ++kc) {
+                const bf16x8 v = p.wpack2[((3 * (wok ? dyw : 0) + dx) * P::KC + kc) * 64 + (wok ? cow : 0) + 32 * hl];
+                wh[dx][kc] = wok ? v : zero;
+            }
+    }
+    static_for<0, 3 * P::KC>([&](auto f_c) {   // the loads land before the row loop (their wait must not sit between the stores)
+        SRHIP_CAPTURE(wh);
+        constexpr int f = decltype(f_c)::value;
+        asm volatile("" : "+v"(wh[f / P::KC][f % P::KC]));
+    });
+    float breg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) breg[e] = (p.bias2 != nullptr && 4 * hl + e < p.cout2) ? p.bias2[4 * hl + e] : 0.0f;
+    const int ne = p.cout2 < 4 ? p.cout2 : 4;   // accumulator registers per dy that hold a real channel in some lane
+    // fragment kc of mid pixel pl + dx of group 0; a group adds 32 pixels = 4096 bytes (the swizzle repeats every 16 pixels)
+    unsigned rd[3][P::KC];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int px = pl + dx;
+#pragma unroll
+        for (int kc = 0; kc < P::KC; ++kc)
+            rd[dx][kc] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(px * 128 + (((2 * kc + hl) ^ ((px >> 1) & 7)) << 4));
+    }
+    const int H = p.h, W = p.w;
+    bf16x8 bq[2][P::KC];
+    f32x16 acc;
+    float s0[NG][4], s1[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s0[g][e] = s1[g][e] = 0.0f;
+
+    PairIter iter = pair_iter_begin(p);
+    PairItem it;
+    while (pair_iter_next(p, iter, it)) {
+        const int x0 = it.x0, y0 = it.y0, nout = it.nout;
+        const unsigned plane = (unsigned)(H * W) * 4u;
+        const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.dst + (long long)it.n * p.cout2 * plane), 0, (int)((unsigned)p.cout2 * plane), 0x00020000);
+        unsigned vo[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int jq = 32 * g + pl, xq = x0 + jq;
+            const bool col_ok = jq < P::TWO && xq < W;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                vo[g][e] = (col_ok && 4 * hl + e < p.cout2) ? (unsigned)(4 * hl + e) * plane + (unsigned)xq * 4u : kOobOffset;
+        }
+
+        auto row_body = [&](auto q_c, const int r) {
+            constexpr int Q = decltype(q_c)::value;                     // s mod NY; mid row r = s - 2 sits in slot Q
+            constexpr int SLOT = ((Q + 2 * P::NY - 2) % P::NY) * P::SLOT_BYTES;
+            const int o = r - 2;                                        // the output row this mid row completes
+            const unsigned soff = (o >= 0 && o < nout) ? (unsigned)((y0 + o) * W) * 4u : kOobOffset;
+            static_for<0, P::KC>([&](auto kc_c) {
+                constexpr int kc = decltype(kc_c)::value;
+                bq[0][kc] = lds_read_b128_off<SLOT>(rd[0][kc]);
+            });
+            static_for<0, 3 * NG>([&](auto st_c) {
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wh); SRHIP_CAPTURE(s0); SRHIP_CAPTURE(s1); SRHIP_CAPTURE(vo);
+                constexpr int st = decltype(st_c)::value;
+                constexpr int g = st / 3, dx = st % 3;
+                constexpr int cur = st & 1, nxt = cur ^ 1;
+                constexpr int gn = (st + 1) / 3, dxn = (st + 1) % 3;
+                lds_wait<0>();
+                static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+                static_for<0, P::KC>([&](auto kc_c) {
+                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wh);
+                    constexpr int kc = decltype(kc_c)::value;
+                    mfma_vv<(dx == 0 && kc == 0)>(acc, wh[dx][kc], bq[cur][kc]);
+                    if constexpr (st + 1 < 3 * NG) bq[nxt][kc] = lds_read_b128_off<SLOT + gn * 4096>(rd[dxn][kc]);
+                });
+                if constexpr (dx == 2) {
+                    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));   // MFMA result -> the vector ALU reads below
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = s1[g][e] + acc[8 + e] + breg[e];
+                        float v = t;
+                        if constexpr (ACT2 == 1) v = fmaxf(t, 0.0f);
+                        else if constexpr (ACT2 == 2) v = fmaxf(t, t * p.slope2);
+                        if (e < ne) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v * p.alpha), dst_rsrc, vo[g][e], soff, 0);
+                        s1[g][e] = s0[g][e] + acc[4 + e];
+                        s0[g][e] = acc[e];
+                    }
+                }
+            });
+        };
+
+        __builtin_amdgcn_s_barrier();  // item start (matches the first layer's)
+        const int nsteps = nout + P::LAG;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += P::NY) {
+            static_for<0, P::NY>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+                if (Q == 0 || s + Q < nsteps) {
+                    __builtin_amdgcn_s_barrier();
+                    if (s + Q >= 2) row_body(q_c, s + Q - 2);
+                }
+            });
+        }
+    }
+}
+
+// HEAD: 0 the residual pair, 1 the head form with two waves per layer (cout2 <= 32), 2 HEAD3 (cout2 <= 8)
+template <bool STORE_MID, int ACT2, int HEAD = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -836,15 +1007,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    if (wave < 2) pair_first_layer<STORE_MID>(p, smem, lds_base, wave, lane);
-    else if constexpr (HEAD) pair_head_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
-    else pair_second_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
+    if constexpr (HEAD == 2) {
+        if (wave < HeadCfg::NW1) pair_first_layer<STORE_MID, HeadCfg>(p, smem, lds_base, wave, lane);
+        else pair_head3_layer<ACT2, HeadCfg>(p, smem, lds_base, lane);
+    } else {
+        if (wave < 2) pair_first_layer<STORE_MID, PairCfg>(p, smem, lds_base, wave, lane);
+        else if constexpr (HEAD == 1) pair_head_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
+        else pair_second_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
+    }
 }
 
-template <bool STORE_MID, int ACT2, bool HEAD = false>
+template <bool STORE_MID, int ACT2, int HEAD = 0>
 int launch_pair(PairParams p, hipStream_t stream)
 {
-    using P = PairCfg;
+    using P = std::conditional_t<HEAD == 2, HeadCfg, PairCfg>;
+    p.two = P::TWO;
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];  // per device
     const int dev = srhip_current_device();
     if (!configured_dev[dev].load(std::memory_order_acquire)) {
@@ -855,7 +1032,7 @@ int launch_pair(PairParams p, hipStream_t stream)
         }
         configured_dev[dev].store(true, std::memory_order_release);
     }
-    // work items = images x vertical segments x 62-column strips, one workgroup per CU walking them; a segment of R
+    // work items = images x vertical segments x TWO-column strips, one workgroup per CU walking them; a segment of R
     // rows costs R + 2 first-layer rows + LAG steps of pipeline fill + the look-ahead's fill latency
     const int slots = srhip_num_cus();
     const int nstrips = srhip_div_up(p.w, P::TWO);
@@ -952,9 +1129,19 @@ SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* a, void* str
     if (a->cout2 != 0 && a->cout2 != 64) {
         SRHIP_REQUIRE(a->cout2 >= 1 && a->cout2 <= 32, "conv3x3_pair: cout2 must be 64 (or 0) or, for the head form, 1..32");
         SRHIP_REQUIRE((long long)a->h * a->w * a->cout2 * 4 < (1ll << 31), "conv3x3_pair: head output too large for 32-bit offsets");
-        if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0, true>(p, s) : launch_pair<false, 0, true>(p, s);
-        if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1, true>(p, s) : launch_pair<false, 1, true>(p, s);
-        return a->mid != nullptr ? launch_pair<true, 2, true>(p, s) : launch_pair<false, 2, true>(p, s);
+        // up to 8 output channels: three first-layer waves and one wave for the narrow layer (SRHIP_PAIR_HEAD=2 in the
+        // environment keeps the two-plus-two form for A/B timing)
+        static const bool head3 = []() { const char* e = getenv("SRHIP_PAIR_HEAD"); return !(e && e[0] == '2'); }();
+        // (the form that also stores `mid` keeps two waves per layer: with the store path's registers the three-wave
+        // first layer spills, and spill traffic would break its hand-counted vector-memory waits)
+        if (a->cout2 <= 8 && head3 && a->mid == nullptr) {
+            if (a->act2 == SRHIP_ACT_NONE) return launch_pair<false, 0, 2>(p, s);
+            if (a->act2 == SRHIP_ACT_RELU) return launch_pair<false, 1, 2>(p, s);
+            return launch_pair<false, 2, 2>(p, s);
+        }
+        if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0, 1>(p, s) : launch_pair<false, 0, 1>(p, s);
+        if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1, 1>(p, s) : launch_pair<false, 1, 1>(p, s);
+        return a->mid != nullptr ? launch_pair<true, 2, 1>(p, s) : launch_pair<false, 2, 1>(p, s);
     }
     if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0>(p, s) : launch_pair<false, 0>(p, s);
     if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1>(p, s) : launch_pair<false, 1>(p, s);

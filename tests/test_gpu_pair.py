@@ -113,10 +113,14 @@ def test_pair_rejects_bad_arguments(F_):
         F_.conv3x3_pair(x, wp, None, wp, None, alpha=0.0)
 
 
-@pytest.mark.parametrize("shape", [(1, 20, 70), (2, 37, 130), (1, 5, 3), (1, 9, 125), (3, 1, 1)])
-@pytest.mark.parametrize("cout2", [3, 8, 32])
+@pytest.mark.parametrize("shape", [(1, 20, 70), (2, 37, 130), (1, 5, 3), (1, 9, 125), (3, 1, 1), (1, 7, 92), (1, 6, 93), (2, 11, 185),
+                                   (1, 40, 300)])
+@pytest.mark.parametrize("cout2", [1, 3, 5, 8, 32])
 def test_pair_head_matches_oracle_and_two_launches(F_, shape, cout2):
-    """Head form: conv 64 -> 64 + ReLU -> conv 64 -> cout2 as fp32 NCHW in one launch (core/models/model.py:111-115)."""
+    """Head form: conv 64 -> 64 + ReLU -> conv 64 -> cout2 as fp32 NCHW in one launch (core/models/model.py:111-115).
+    Up to 8 output channels without the intermediate map stored run as three first-layer waves plus one wave that
+    sums the kernel rows in registers (92-column strips: widths around 92 / 184 meet its strip borders); the other
+    cases keep two waves per layer.  The two differ in the fp32 summation order only."""
     from oracle import oracle as orc
     n, h, w = shape
     x, w1, b1, w2, b2 = _case(300 * h + w + cout2, n, h, w)
@@ -128,7 +132,9 @@ def test_pair_head_matches_oracle_and_two_launches(F_, shape, cout2):
     out_nomid = F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), cout2)
     torch.cuda.synchronize()
     assert tuple(out.shape) == (n, cout2, h, w) and out.dtype == torch.float32
-    assert torch.equal(out, out_nomid)
+    assert bool(torch.isfinite(out_nomid).all())
+    assert float((out - out_nomid).abs().max()) <= 1e-4
+    assert torch.equal(out_nomid, F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), cout2)), "not repeatable"
     # the two launches it replaces, on the kernel's own intermediate map: same arithmetic up to the summation order
     ref2 = F_.conv3x3(mid, wp2, b2.cuda(), cout2, act=F_.ACT_NONE, out_nchw_f32=True)
     assert float((out - ref2).abs().max()) <= 1e-4
@@ -141,6 +147,41 @@ def test_pair_head_matches_oracle_and_two_launches(F_, shape, cout2):
     assert np.abs(out.cpu().numpy() - ref).max() <= 2e-2      # a few intermediate elements land on the neighbouring bf16 value
     ref_own = orc.conv2d(mid.float().permute(0, 3, 1, 2).cpu().numpy(), w2.numpy(), b2.numpy(), 1, 1)
     assert np.abs(out.cpu().numpy() - ref_own).max() <= 1e-3  # the fp32-accumulate bar on the kernel's own intermediate map
+    assert np.abs(out_nomid.cpu().numpy() - ref_own).max() <= 1e-3
+
+
+@pytest.mark.parametrize("act2,alpha", [(1, 1.0), (2, 0.5), (0, 0.2)])
+def test_pair_head_activation_scale_and_zero_padding(F_, act2, alpha):
+    """The narrow layer's epilogue (activation, alpha) and the zero padding of the intermediate map on every border and
+    at every segment / strip seam: a large first-layer bias makes 'first layer evaluated on padding' differ from zeros
+    by far more than the tolerance."""
+    from oracle import oracle as orc
+    n, h, w, cout2 = 1, 70, 190, 3
+    x, w1, b1, w2, b2 = _case(17 + act2, n, h, w)
+    b1 = b1 + 2.0
+    w2, b2 = w2[:cout2].contiguous(), b2[:cout2].contiguous()
+    xc = x.cuda()
+    wp1, wp2 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64), F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    out, mid = F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), cout2, act2=act2, slope2=0.05, alpha=alpha, keep_mid=True)
+    out3 = F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), cout2, act2=act2, slope2=0.05, alpha=alpha)
+    ref = orc.conv2d(mid.float().permute(0, 3, 1, 2).cpu().numpy(), w2.numpy(), b2.numpy(), 1, 1, act=act2, slope=0.05) * np.float32(alpha)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-3      # values ~10x larger (bias 2.0)
+    assert np.abs(out3.cpu().numpy() - ref).max() <= 2e-3
+
+
+def test_pair_head_full_size_partitions(F_):
+    """4K and a many-image shape: the two-class and range partitions of the 92-column strips; the three-wave form
+    against the two-plus-two form (which stores the intermediate map) on device-generated data."""
+    _, w1, b1, w2, b2 = _case(5, 1, 8, 8)
+    w2, b2 = w2[:3].contiguous(), b2[:3].contiguous()
+    wp1, wp2 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64), F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    for n, h, w in ((1, 2160, 3840), (16, 512, 1024), (9, 600, 1000)):
+        g = torch.Generator(device="cuda").manual_seed(h + n)
+        xc = (torch.rand(n, h, w, 64, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+        out3 = F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), 3)
+        out2, _ = F_.conv3x3_pair_head(xc, wp1, b1.cuda(), wp2, b2.cuda(), 3, keep_mid=True)
+        assert bool(torch.isfinite(out3).all())
+        assert float((out3 - out2).abs().max()) <= 1e-4, (n, h, w)
 
 
 def test_pair_head_rejects_bad_arguments(F_):
