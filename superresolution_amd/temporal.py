@@ -33,6 +33,43 @@ def _add(a: Tensor, b: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# Recording of the stored maps of one pass (tests: a bf16-storage oracle's backward is run on the very maps this pass
+# stored, so that both take the same ReLU decisions).  Keys: "<module path>#<k-th call in the pass>" for a layer's
+# output, a few fixed names for the rest.  Values: (tensor, number of real channels) for NHWC bf16 maps, (tensor, None)
+# for fp32 NCHW tensors.
+# ------------------------------------------------------------------------------------------------
+_TRACE = None
+
+
+class trace_maps:
+    def __init__(self, model: nn.Module, store: dict) -> None:
+        self.state = {"names": {id(m): n for n, m in model.named_modules()}, "count": {}, "maps": store}
+
+    def __enter__(self):
+        global _TRACE
+        _TRACE = self.state
+        return self.state["maps"]
+
+    def __exit__(self, *exc):
+        global _TRACE
+        _TRACE = None
+        return False
+
+
+def _rec(where, t: Tensor, channels=None, suffix: str = "") -> Tensor:
+    if _TRACE is not None:
+        if isinstance(where, str):
+            key = where
+        else:
+            base = _TRACE["names"][id(where)] + suffix
+            k = _TRACE["count"].get(base, 0)
+            _TRACE["count"][base] = k + 1
+            key = f"{base}#{k}"
+        _TRACE["maps"][key] = (t.detach(), channels)
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
 # parameter containers with the reference's module tree
 # ------------------------------------------------------------------------------------------------
 class GradientMap(nn.Module):
@@ -54,9 +91,13 @@ class ConvActivation(nn.Sequential):
     def run(self, x: Tensor, res: Tensor = None) -> Tensor:
         c = self[0]
         if torch.is_grad_enabled():   # training graph: the same launch as a differentiable operator
-            y = A_.conv2d(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU)
+            y = _rec(self, A_.conv2d(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU), c.out_channels)
             return y if res is None else A_.add(y, res)
-        return F_.conv2d_auto(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU, res=res)
+        if _TRACE is not None and res is not None:   # recorded passes keep the layer's own output apart from the sum
+            y = _rec(self, F_.conv2d_auto(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU), c.out_channels)
+            return F_.add_bf16(y, res)
+        return _rec(self, F_.conv2d_auto(x, c.weight, c.bias, stride=c.stride[0], padding=c.padding[0], act=F_.ACT_RELU, res=res),
+                    c.out_channels)
 
 
 class TransConvActivation(nn.Sequential):
@@ -72,8 +113,8 @@ class TransConvActivation(nn.Sequential):
             w1 = c.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)
             y = A_.conv2d(x, w1, c.bias.repeat(4), stride=1, padding=0, act=F_.ACT_RELU)
             n, h, w, _ = x.shape
-            return y[..., :4 * cout].reshape(n, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, cout).contiguous()
-        return F_.conv_transpose2x2s2_auto(x, c.weight, c.bias, act=F_.ACT_RELU)
+            return _rec(self, y[..., :4 * cout].reshape(n, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, cout).contiguous(), cout)
+        return _rec(self, F_.conv_transpose2x2s2_auto(x, c.weight, c.bias, act=F_.ACT_RELU), c.weight.shape[1])
 
 
 def _run_seq(seq: nn.Sequential, x: Tensor, addend: Tensor = None) -> Tensor:
@@ -149,10 +190,10 @@ class GBuffersEncoder(nn.Module):
             e = m.run(e)
         last = self.conv_enhance[-1][0]
         if torch.is_grad_enabled():   # enhance_param is trained: the scale and the add stay visible to autograd
-            y = A_.conv2d(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU)
+            y = _rec(self.conv_enhance[-1], A_.conv2d(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU), last.out_channels)
             # the scale stays fp32 (inference passes float(enhance_param) as the epilogue's alpha and rounds the sum
             # once): the product and the sum are formed in fp32, and enhance_param's gradient is an fp32 reduction
-            return (fmap.float() + self.enhance_param * y.float()).to(torch.bfloat16), vmax
+            return _rec("buffers_encoder.out", (fmap.float() + self.enhance_param * y.float()).to(torch.bfloat16), fmap.shape[-1]), vmax
         # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
         return F_.conv2d_auto(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU,
                               alpha=self._enhance_scale(), res=fmap), vmax
@@ -275,10 +316,15 @@ class MainNetwork(nn.Module):
             folded = F_.pixel_unshuffle_to_nhwc_bf16(gfull, self.sr_scale)
         grad, g_self, g_cross = self.attn_grad.run(folded)
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
-        if torch.is_grad_enabled():   # model_final.py:422 as written, on the bf16 maps (gates broadcast over the channels)
-            cur = fmap_current + torch.sigmoid(f_self * g_cross) * fmap + torch.sigmoid(g_self * f_cross) * grad
+        _rec("main_network.grad_map", folded, 6 * self.sr_scale ** 2)
+        if torch.is_grad_enabled():
+            # model_final.py:422 (gates broadcast over the channels), formed in fp32 and rounded once like the inference
+            # kernel's; the gradients re-enter the bf16 maps through the casts
+            cur = (fmap_current.float() + torch.sigmoid(f_self.float() * g_cross.float()) * fmap.float()
+                   + torch.sigmoid(g_self.float() * f_cross.float()) * grad.float()).to(torch.bfloat16)
         else:                         # ... as one kernel
             cur = F_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)
+        _rec("main_network.cur", cur, cur.shape[-1])
         return self.main_network.run((cur, fmap_history, fmap_gbuffer))
 
 
@@ -350,6 +396,10 @@ class SuperSampler(nn.Module):
             marked_frames, aux_buffer, enhance_weight = F_.disocclusion(lr_frame.float(), lr_buffer.float(), warped_frames.float(),
                                                                         warped_buffer.float(), aux_planes=16 if b * f == 1 else 14)
             aux_motion = motion_vectors.reshape(b * f, -1, h, w)
+            _rec("pre.marked_frames", marked_frames)
+            _rec("pre.aux", aux_buffer[:, :14].clone())
+            _rec("pre.motion", aux_motion)
+            _rec("pre.enhance_weight", enhance_weight)
             fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames))[0]
         fmap_history = self.history_refiner.run(fmap_history, aux_buffer, aux_motion)          # (b*f, h, w, hs)
         if f > 1:  # (b, f*hs, h, w) in the reference: history index major, then channels
@@ -358,10 +408,10 @@ class SuperSampler(nn.Module):
         fmap = self.main_network.run(fmap_current, fmap_history, fmap_bf, hr_buffer)
         c0, c2 = self.conv_out[0], self.conv_out[2]
         if training:
-            t = A_.conv2d((fmap, fmap_shadow), c0.weight, c0.bias)
+            t = _rec("conv_out.0", A_.conv2d((fmap, fmap_shadow), c0.weight, c0.bias), c0.out_channels)
             hr = A_.pixel_shuffle_out(t, self.frame_ch, self.sr_scale)                         # (b, 3, H, W) fp32
             x16 = nn.functional.pad(hr.permute(0, 2, 3, 1), (0, 16 - self.frame_ch)).to(torch.bfloat16).contiguous()
-            y = A_.conv2d(x16, c2.weight, c2.bias, act=F_.ACT_RELU)
+            y = _rec("conv_out.2", A_.conv2d(x16, c2.weight, c2.bias, act=F_.ACT_RELU), self.frame_ch)
             sr_frame = y[..., :self.frame_ch].permute(0, 3, 1, 2).float()
             assert depth_max < 10, "Depth value is too large"
             return sr_frame, enhance_weight

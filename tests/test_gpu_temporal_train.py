@@ -5,14 +5,16 @@ of every parameter under an enhance-weighted L1 term plus a dense linear term). 
 +-1 vectors and, for tensors of at most 4,096 elements, the tensor itself.  The projections of the difference estimate
 its norm (E[(v.e)^2] = |e|^2 for a +-1 vector v).
 
-Bars.  The GPU path stores every activation and activation gradient as bf16 against the reference's fp32 (1-2 % in the
-default network's gradients), and no bf16-storage oracle exists for this network, so the comparison is with the fp32
-reference and the bar follows the number of pixels a gradient is summed over: the U-shaped main stage works at 1/2, 1/4
+Bars.  The parity proof is test_temporal_gradients_against_the_bf16_storage_oracle below: the oracle
+(oracle/temporal_emul.py, whose fp32 mode tests/test_temporal_emul_cpu.py pins to this fixture at 3e-4) rounds where the
+GPU path stores bf16 and runs its backward on the GPU pass's own stored maps, and every one of the 113 tensors is held to
+rel <= 2e-2, cosine >= 0.999.  The comparison with the fp32 reference itself stays as a guard; its bar follows the
+number of pixels a gradient is summed over: the U-shaped main stage works at 1/2, 1/4
 and 1/8 of the LR size, where this input leaves 24 x 32, 12 x 16 and 6 x 8 pixels, and a bf16 rounding or a ReLU that
 flips at a value within rounding of zero moves such a sum by whole percents (at LR 16 x 24 the same tensors are 1.3-3
 times further off, the large ones 1.5 times: the error falls with the pixel count, which a wrong formula's would not).
-Per tensor: relative error <= 3e-2, <= 6e-2 at 1/2, <= 8e-2 at 1/4 and for the four one-channel gate layers, <= 0.15 at
-1/8; over all tensors together (error and gradient norms summed in squares) <= 1.5e-2; every norm within 10 %."""
+Per tensor: relative error <= 3e-2, <= 6e-2 at 1/2, <= 8e-2 at 1/4, <= 0.15 at 1/8 (the four one-channel gate layers: see
+_bar); over all tensors together (error and gradient norms summed in squares) <= 1.5e-2; every norm within 10 %."""
 import os
 import sys
 
@@ -29,7 +31,13 @@ from seeded_inputs import temporal_train_inputs  # noqa: E402
 def _bar(name: str) -> float:
     if any(k in name for k in (".conv3.", ".up3.", ".down3.")):
         return 0.15
-    if any(k in name for k in (".conv2.", ".up2.", ".down2.", ".w_self.", ".w_cross.")):
+    if any(k in name for k in (".w_self.", ".w_cross.")):
+        # the four one-channel gate layers (gradient norms 1e-9 .. 1e-6 beside 1e-1 elsewhere: sums of cancelling terms).
+        # In the bf16-storage oracle itself, moving 3 % of ONE feature map's elements by one bf16 step moves these
+        # gradients by 6 - 25 % and the output layer's by 0.3 %: against the fp32 reference they are only guarded
+        # against gross errors; their parity bar is the oracle test's 2e-2.
+        return 0.5
+    if any(k in name for k in (".conv2.", ".up2.", ".down2.")):
         return 8e-2
     if any(k in name for k in ("main_network.main_network.conv1.", "main_network.main_network.down1.", "main_network.main_network.up1.")):
         return 6e-2
@@ -99,11 +107,66 @@ def test_temporal_training_gradients_golden():
     for rel, name, norm_ref, norm_gpu in _tensor_errors(m, t):
         err2 += (rel * norm_ref) ** 2
         ref2 += norm_ref ** 2
-        assert abs(norm_gpu - norm_ref) <= 0.10 * norm_ref + 1e-12, (name, norm_gpu, norm_ref)
+        # (norms of gradients four and more orders of magnitude under the largest are sums of cancelling terms at bf16 storage:
+        # they are held to the bf16-storage oracle below, not to this guard)
+        if norm_ref >= 1e-5:
+            assert abs(norm_gpu - norm_ref) <= 0.10 * norm_ref + 1e-12, (name, norm_gpu, norm_ref)
         worst.append((rel / _bar(name), rel, name, norm_ref))
     worst.sort(reverse=True)
     assert worst[0][0] <= 1.0, worst[:8]
     assert (err2 / ref2) ** 0.5 <= 1.5e-2, (err2 / ref2) ** 0.5
+
+
+def _nchw(rec):
+    """A recorded map of the GPU pass as the oracle's NCHW fp32 tensor."""
+    t, c = rec
+    if c is None:
+        return t.float().cpu()
+    return t[..., :c].permute(0, 3, 1, 2).float().cpu().contiguous()
+
+
+def test_temporal_gradients_against_the_bf16_storage_oracle():
+    """All 113 parameter gradients of the HIP training graph against oracle/temporal_emul.py in its bf16-storage mode,
+    its backward run on the GPU pass's own stored maps (same ReLU decisions): rel <= 2e-2 and cosine >= 0.999 per
+    tensor.  The forward maps themselves are checked against the UNFORCED emulation: within a few bf16 steps each."""
+    from oracle import temporal_emul as TE
+    from superresolution_amd.temporal import trace_maps
+    from tests.test_temporal_emul_cpu import cpu_model, loss_fn
+    m, args, target, G = _model_and_inputs()
+    m.train()
+    rec = {}
+    with trace_maps(m, rec):
+        sr, ew = m(*[a.clone() for a in args])
+    _loss(sr, ew, target, G).backward()
+    gpu = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    forced = {k: _nchw(v) for k, v in rec.items()}
+
+    cm = cpu_model()
+    cargs, ctarget, cG = temporal_train_inputs(48, 64)
+    own = {}
+    TE.forward(cm, cargs, emulate=True, trace=own)
+    assert len(forced) >= 60 and set(forced) <= set(own), sorted(set(forced) - set(own))
+    for k, v in forced.items():
+        ref = own[k]
+        assert v.shape == ref.shape, (k, v.shape, ref.shape)
+        if k.startswith("pre."):
+            assert float((v - ref).abs().max()) <= 1e-4 or float(((v - ref).abs() > 1e-4).float().mean()) <= 2e-3, k   # fp32 input-side tensors
+            continue
+        tol = 2.0 ** -6 * max(1.0, float(ref.abs().max()))      # four bf16 steps at the map's magnitude
+        assert float((v - ref).abs().max()) <= tol, (k, float((v - ref).abs().max()), tol)
+
+    sr_o, ew_o, loss_o, grads = TE.forward_backward(cm, cargs, loss_fn(ctarget, cG), emulate=True, forced=forced)
+    assert float((sr.detach().cpu() - sr_o).abs().max()) == 0.0       # the last layer's stored map is forced
+    worst = []
+    for n, g in gpu.items():
+        ref = grads[n]
+        nr = float(ref.norm())
+        rel = float((g - ref).norm()) / max(nr, 1e-30)
+        cos = float((g * ref).sum()) / max(float(g.norm()) * nr, 1e-30)
+        worst.append((rel, 1.0 - cos, n, nr))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 2e-2, worst[:6]
+    assert max(w[1] for w in worst) <= 1e-3, sorted(worst, key=lambda w: -w[1])[:6]
 
 
 def test_temporal_gradient_error_falls_with_the_pixel_count():
