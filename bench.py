@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "temporal_train", "recurrent", "reprfn", "reprfn_train", "memops"])
+    ap.add_argument("--workload", default="infer4k", choices=["infer4k", "train", "temporal", "temporal_train", "recurrent", "reprfn", "reprfn_train", "memops", "seq64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg of the default workload")
     ap.add_argument("--no-aux", action="store_true", help="skip the short runs of the other workloads in the default line")
@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--train-batch", type=int, default=16, help="crops per GPU per step (train workload)")
     ap.add_argument("--train-crop", type=int, default=1024, help="HR crop size (train workload)")
     ap.add_argument("--cpu-train-crop", type=int, default=1024, help="HR crop size of the CPU training-step sample")
+    ap.add_argument("--seq-frames", type=int, default=64, help="frames of the sequence (seq64 workload), sharded over the ranks")
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[288, 384], help="LR crop (h w) of the CPU-oracle sample")
     return ap.parse_args()
 
@@ -700,13 +701,105 @@ def run_aux_infer(args, world, rank, dev, dist):
                          "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None}}
 
 
+def run_seq64(args, world, rank, dev, dist):
+    """BASELINE configs[4]: batched offline up-scaling of a synthetic 64-frame sequence, frame i -> GPU i mod world
+    (superresolution_amd.dp.shard_range), no collective.  The frames are DISTINCT and live in pinned host memory as fp16
+    CHW arrays (the reference's on-disk format, core/data/supersampling_sequence.py:153-169; batch layout
+    core/trainer.py:86-113: the network reads the last frame of `lr_frames` / `hr_buffers`).  Two timings of the whole
+    shard, max over ranks: `value` with the shard already resident in HBM (decode + network per frame), and
+    `with_upload` where every frame crosses PCIe on a side stream, double buffered, while the previous one computes."""
+    from superresolution_amd.dp import shard_range
+    from superresolution_amd.feeder import FrameStreamer, decode_crop_flip
+    model = make_model(dev)
+    mine = list(shard_range(args.seq_frames, rank, world))
+    frames = []
+    for i in mine:   # generated on the GPU (seeded per frame index, whatever rank owns it), parked in pinned host memory
+        g = torch.Generator(device=dev).manual_seed(1000 + i)
+        lr16 = torch.rand(3, LR_H, LR_W, device=dev, generator=g).half()
+        hb16 = torch.rand(10, HR_H, HR_W, device=dev, generator=g).half()
+        frames.append({"lr": lr16.cpu().pin_memory(), "hb": hb16.cpu().pin_memory()})
+    del lr16, hb16
+    torch.cuda.empty_cache()
+
+    def sums_of(outs):
+        return torch.stack(outs).cpu().tolist()
+
+    # (a) shard resident in HBM as fp16
+    resident = [{k: t.to(dev) for k, t in fr.items()} for fr in frames]
+    lr32 = torch.empty(1, 3, LR_H, LR_W, device=dev)
+    hb32 = torch.empty(1, 10, HR_H, HR_W, device=dev)
+
+    def pass_resident():
+        outs = []
+        for fr in resident:
+            decode_crop_flip(fr["lr"], out=lr32[0])
+            decode_crop_flip(fr["hb"], out=hb32[0])
+            outs.append(model.infer(lr32, hb32).double().sum())
+        return outs
+
+    streamer = FrameStreamer(frames, dev)
+
+    def pass_streamed():
+        return [model.infer(fr["lr"], fr["hb"]).double().sum() for fr in streamer]
+
+    def timed(fn):
+        fn()   # warm-up pass over the shard
+        settle_host()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, sums_of(outs)
+
+    with torch.no_grad():
+        dt_res, sums_res = timed(pass_resident)
+        dt_up, sums_up = timed(pass_streamed)
+    assert all(map(lambda v: v == v and abs(v) < 1e12, sums_res)) and sums_res == sums_up, "streamed frames differ from resident ones"
+    assert len(set(sums_res)) == len(sums_res), "the frames of the sequence are not distinct"
+    if rank != 0:
+        return None
+    n = args.seq_frames
+    flop_frame = FLOP_PER_HR_PX * HR_H * HR_W + FLOP_PER_LR_PX * LR_H * LR_W
+    tflops = n * flop_frame / 1e12 / dt_res / world
+    host_bytes = sum(t.numel() * 2 for t in frames[0].values())
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_memops
+    res = {"metric": "4K output frames/sec (4x fwd, 1 GPU) + train crops/sec at 1/2/4/8 GPUs", "value": n / dt_res, "unit": "frames/s",
+           "n_gpus": world, "steps": n, "warmup": len(mine), "ms_per_step": dt_res / len(mine) * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"offline up-scaling of a {n}-frame sequence of distinct 540x960 -> 2160x3840 frames, frame i on GPU i mod "
+                                  f"{world}, shard resident in HBM as fp16 CHW (decode + default SuperSampler per frame)",
+                      "frames": n, "frames_per_gpu": len(mine), "tflop_per_frame": flop_frame / 1e12},
+           "with_upload": {"value": n / dt_up, "unit": "frames/s", "ms_per_frame_per_gpu": dt_up / len(mine) * 1e3,
+                           "host_bytes_per_frame": host_bytes, "pcie_gbps_per_gpu": host_bytes * len(mine) / dt_up / 1e9,
+                           "sample": "the same shard streamed from pinned host memory: frame k+1 uploads on a side stream into the other "
+                                     "of two staging sets while frame k computes (superresolution_amd.feeder.FrameStreamer)"},
+           "roofline": {"bound": "mfma", "kernel": "whole network per GPU (default SuperSampler, 14.82 TFLOP per frame, over the wall time "
+                        "of the shard incl. the fp16 decode)", "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None}}
+    res.update(bench_memops.headline())
+    return res
+
+
 def run_other_workloads(args, dev):
     """Short runs of the other workloads of the path (each is `--workload NAME` on its own) so that one default line
     carries a number and a roofline fraction for every network: same code, same validation (finite, bit-reproducible /
     loss falling), fewer timed steps.  Single GPU only; a failure is recorded, the headline is printed regardless."""
     import argparse
     out = {}
-    for name, steps, warmup in (("temporal", 20, 5), ("reprfn", 40, 10), ("recurrent", 12, 3), ("temporal_train", 6, 2), ("reprfn_train", 12, 3)):
+    for name, steps, warmup in (("temporal", 20, 5), ("reprfn", 40, 10), ("recurrent", 12, 3), ("temporal_train", 6, 2), ("reprfn_train", 12, 3),
+                                ("seq64", 64, 64)):
         a = argparse.Namespace(**vars(args))
         a.workload, a.steps, a.warmup = name, steps, warmup
         try:
@@ -714,10 +807,14 @@ def run_other_workloads(args, dev):
                 r = run_temporal_train(a, 1, 0, dev, None)
             elif name == "reprfn_train":
                 r = run_reprfn_train(a, 1, 0, dev, None)
+            elif name == "seq64":
+                r = run_seq64(a, 1, 0, dev, None)
             else:
                 r = run_aux_infer(a, 1, 0, dev, None)
             out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": steps,
                          "frac_of_bf16_mfma_peak": r["roofline"]["frac"], "workload": r["config"]["workload"]}
+            if "with_upload" in r:
+                out[name]["with_upload"] = {k: r["with_upload"][k] for k in ("value", "unit", "pcie_gbps_per_gpu")}
         except Exception as e:
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
@@ -827,6 +924,14 @@ def main():
 
     if args.workload == "reprfn_train":
         res = run_reprfn_train(args, world, rank, dev, dist)
+        if rank == 0:
+            emit(args, res)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "seq64":
+        res = run_seq64(args, world, rank, dev, dist)
         if rank == 0:
             emit(args, res)
         if dist is not None:

@@ -96,3 +96,38 @@ def test_gbuffer_schema_and_motion_vector_decode():
     assert mv.shape == (2, 4, 6) and mv.dtype == np.float32
     assert np.allclose(mv[0], -(rgb[0] - 0.5) * 3.0) and np.allclose(mv[1], (rgb[1] - 0.5) * 2.0)
     assert np.array_equal(decode_motion_vector(np.full((3, 2, 2), 0.5, np.float32)), np.zeros((2, 2, 2), np.float32))
+
+
+@pytest.mark.gpu
+def test_frame_streamer_sharded_sequence_equals_sequential_bit_for_bit():
+    """BASELINE's batched-sequence case: distinct frames in pinned host memory, frame i owned by rank i mod world,
+    every rank streaming its shard through two staging sets (upload of frame k+1 beside the network on frame k).  The
+    outputs equal, bit for bit, what one process computes frame by frame from device-resident copies -- whatever the
+    sharding, and also when the streamer is walked a second time (its buffers are re-used)."""
+    import torch
+    from superresolution_amd import SuperSampler
+    from superresolution_amd.dp import shard_range
+    from superresolution_amd.feeder import FrameStreamer
+    torch.manual_seed(42)
+    m = SuperSampler(3, 10, 1).cuda().eval()
+    n, h, w = 7, 40, 72
+    g = torch.Generator().manual_seed(3)
+    frames = [{"lr": torch.rand(3, h, w, generator=g).half().pin_memory(), "hb": torch.rand(10, 4 * h, 4 * w, generator=g).half().pin_memory()}
+              for _ in range(n)]
+    with torch.no_grad():
+        ref = [m.infer(fr["lr"].cuda().float()[None], fr["hb"].cuda().float()[None]).clone() for fr in frames]
+        assert len({float(r.double().sum()) for r in ref}) == n
+        for world in (1, 2, 3):
+            seen = []
+            for rank in range(world):
+                mine = list(shard_range(n, rank, world))
+                st = FrameStreamer([frames[i] for i in mine])
+                for rep in range(2):
+                    outs = [m.infer(fr["lr"], fr["hb"]).clone() for fr in st]
+                    assert len(outs) == len(mine)
+                    for i, o in zip(mine, outs):
+                        assert torch.equal(o, ref[i]), (world, rank, i, rep)
+                seen += mine
+            assert sorted(seen) == list(range(n))
+    with pytest.raises(TypeError):
+        FrameStreamer([{"lr": torch.zeros(3, 4, 4)}])
