@@ -97,6 +97,51 @@ class FlatGradAllReducer:
         module._grad_reducer = self
         return self
 
+    def attach_hooks(self) -> "FlatGradAllReducer":
+        """Gather mode with overlap, for networks whose backward is assembled from per-operator autograd nodes (the
+        temporal network's 113 parameters, RepRFN's 264): a post-accumulate hook on every parameter tells the reducer
+        when autograd has finished that parameter's gradient; when a bucket's last one has arrived its gradients move
+        into the flat buffer with ONE multi-tensor copy, the parameters' ``.grad`` are re-pointed at the views and the
+        bucket's all-reduce starts while autograd is still working through the earlier layers.  Buckets complete in
+        reverse parameter order, as backward visits the layers.  Parameters that receive no gradient in a step are
+        picked up by ``all_reduce()`` (zeros)."""
+        if not self.gather:
+            raise ValueError("attach_hooks: the in-place mode is announced by the backward itself (attach / mark_ready)")
+        if getattr(self, "_hooks", None):
+            return self
+        self._hooks = [p.register_post_accumulate_grad_hook(self._grad_arrived) for p in self.params]
+        return self
+
+    def _grad_arrived(self, p: Tensor) -> None:
+        i = self._index.get(id(p))
+        if i is None or self._defer:
+            return
+        b = self.bucket_of[i]
+        if self._launched[b] and self._collective_needed():
+            raise RuntimeError("FlatGradAllReducer: a gradient arrived for a bucket that is already being reduced "
+                               "(second backward of a step without no_sync()?)")
+        if self._ready[i]:
+            return
+        self._ready[i] = True
+        self._left[b] -= 1
+        if self._left[b] == 0:
+            self._collect_bucket(b)
+            self._launch(b)
+
+    def _collect_bucket(self, b: int) -> None:
+        src, dst = [], []
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if self.bucket_of[i] != b or p.grad is v:
+                continue
+            if p.grad is None:
+                v.zero_()
+            else:
+                src.append(p.grad)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+
     def grad_view(self, p: Tensor) -> Optional[Tensor]:
         i = self._index.get(id(p))
         return None if i is None else self.views[i]

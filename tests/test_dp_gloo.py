@@ -284,3 +284,73 @@ def test_single_rank_second_backward_is_not_refused():
             red.mark_ready(p)
     red.all_reduce()
     assert torch.equal(red.flat, torch.full((5,), 2.0))
+
+
+def _hook_worker(rank, world, port, q):
+    """Gather mode with post-accumulate hooks (the temporal network's and RepRFN's reducer): buckets start from inside
+    torch autograd's backward, last layers first, and the reduced buffer equals the plain gather mode's bit for bit;
+    a parameter that receives no gradient is picked up by all_reduce(); accumulation runs under no_sync()."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from superresolution_amd.dp import FlatGradAllReducer, broadcast_parameters
+        torch.manual_seed(9)
+        def make():
+            torch.manual_seed(9)
+            return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(),
+                                       torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+        g = torch.Generator().manual_seed(50 + rank)
+        x, y = torch.randn(2, 3, 8, 8, generator=g), torch.randn(2, 2, 8, 8, generator=g)
+        out = {}
+        for mode in ("plain", "hooks"):
+            net = make()
+            unused = torch.nn.Parameter(torch.ones(3))
+            broadcast_parameters(net, src=0)
+            red = FlatGradAllReducer(list(net.parameters()) + [unused], gather=True, buckets=3)
+            if mode == "hooks":
+                red.attach_hooks()
+            logs = []
+            for step in range(2):
+                red.zero_grad()
+                torch.nn.functional.mse_loss(net(x), y).backward()
+                in_backward = list(red.launch_log)
+                red.all_reduce()
+                red.check_views()
+                logs.append((in_backward, list(red.launch_log)))
+            # two backward passes in one step
+            red.zero_grad()
+            with red.no_sync():
+                torch.nn.functional.mse_loss(net(x), y).backward()
+                deferred = list(red.launch_log)
+            torch.nn.functional.mse_loss(net(2 * x), y).backward()
+            red.all_reduce()
+            out[mode] = (red.flat.clone().numpy(), logs, deferred, red.n_buckets)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_hooked_gather_mode_overlaps_and_equals_plain_gather_mode():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hook_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, out in res:
+        flat_p, logs_p, _, nb = out["plain"]
+        flat_h, logs_h, deferred, _ = out["hooks"]
+        assert nb == 3
+        assert (flat_p == flat_h).all(), "hooked buckets changed the reduced gradients"
+        for in_bw, after in logs_p:
+            assert in_bw == [] and after == [2, 1, 0]
+        for in_bw, after in logs_h:
+            # the last bucket holds the unused parameter: only all_reduce() can complete it; the others start in backward
+            assert in_bw == [1, 0] and after == [1, 0, 2], (in_bw, after)
+        assert deferred == []
+    assert (res[0][1]["hooks"][0] == res[1][1]["hooks"][0]).all()
