@@ -643,12 +643,18 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_kernel(const ConvPa
 // Cfg<6, 2, 2> above splits that layer over OUTPUT channels: a wave holds one 32-channel tile for all 96 input channels,
 // so every pixel fragment it reads from LDS feeds a single MFMA -- four waves then ask the LDS for 128 bytes per clock
 // at full matrix rate, its whole bandwidth, and the layer ran LDS-bound.  Here a wave holds BOTH output tiles for HALF
-// of the input channels (k-chunks {A0, A1, B0} or {B1, B2, B3}: 216 registers of weights either way), every fragment
-// feeds two MFMAs, and the two partial accumulators meet in the fp32 staging area the epilogue crosses anyway: each wave
-// stages its 32 x 64 partial, and after the next row's barrier finishes HALF of the pixel group's store groups from the
-// sum of both partials.  Staging is double buffered by row parity (the partner may still be reading row i - 1 when
-// this wave stages row i).  ReLU / bias / alpha epilogue, bf16 NHWC output, no residual and no sign-bit forms: what
-// the network's two concat layers need.
+// of the input channels (k-chunks {A0, A1, B0} or {B1, B2, B3}: 216 registers of weights either way, all in AGPRs), every
+// fragment feeds two MFMAs, and the partial accumulators meet in the fp32 staging area the epilogue crosses anyway:
+// wave kh FINISHES output tile kh of its 32 pixels (bias, activation, alpha, bf16 pack, 16-byte stores) from its own
+// partial of that tile and the partner's.
+//   * No accumulator is staged outside the MFMA stream.  Taps 0 and 8 run tile-major.  In tap 8 the partner's tile comes
+//     first and is staged (into the `give` area the partner reads after the next row's barrier, double buffered by row
+//     parity) in the gaps behind the own tile's MFMAs; the own tile, complete with the row's last MFMA, is staged in the
+//     first gaps of the NEXT row's tap 0, whose first three MFMAs belong to the partner's tile.
+//   * Ring slots enter the fragment reads through the instruction's offset field: the row loop is unrolled over the six
+//     slots, and two sets of lane addresses (slots 0..2 / 3..5) keep every offset under 64 KiB.
+// ReLU / bias / alpha epilogue, bf16 NHWC output, no residual and no sign-bit forms: what the network's two concat
+// layers need.
 // ------------------------------------------------------------------------------------------------------------------
 struct KsCfg {
     using L = Cfg<6, 2, 2, false, 0, 0>;                // LDS row image, LDS-DMA pieces and strip width of the concat layer
@@ -656,10 +662,11 @@ struct KsCfg {
     static constexpr int NWAVES = 4, TW = L::TW;
     static constexpr int LA = L::LA, RING = L::RING, SLOT_BYTES = L::SLOT_BYTES, RING_BYTES = L::RING_BYTES;
     static constexpr int NPIECE = L::NPIECE, MAXP = L::MAXP;
-    static constexpr int PXS = 256;                     // staged bytes per pixel (64 fp32)
-    static constexpr int STAGE_BYTES = 32 * PXS;        // per wave and row parity
-    static constexpr int STAGE_OFF = RING_BYTES;        // [parity][wave]
-    static constexpr int DUMMY_OFF = STAGE_OFF + 2 * NWAVES * STAGE_BYTES;
+    static constexpr int PXS = 128;                     // staged bytes per pixel of ONE 32-channel tile (fp32)
+    static constexpr int TILE_BYTES = 32 * PXS;         // 4 KiB
+    static constexpr int GIVE_OFF = RING_BYTES;         // [row parity][wave]: partial of the partner's tile
+    static constexpr int OWN_OFF = GIVE_OFF + 2 * NWAVES * TILE_BYTES;   // [wave]: partial of the own tile
+    static constexpr int DUMMY_OFF = OWN_OFF + NWAVES * TILE_BYTES;
     static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
     // vector-memory operations of one row and wave, in issue order: LDS-DMA pieces in taps 0..MAXP-1, the two stores in
     // taps 4 and 8
@@ -667,8 +674,18 @@ struct KsCfg {
     static constexpr int WAIT_STEADY = (VM_ROW - MAXP) + (LA - 3) * VM_ROW;
     static constexpr int WAIT_EARLY = (LA - 4) * MAXP + VM_ROW < (LA - 3) * VM_ROW ? (LA - 4) * MAXP + VM_ROW : (LA - 3) * VM_ROW;
     static_assert(MAXP <= 4 && LA == 5 && WAIT_STEADY <= 63, "stores sit in taps 4 and 8 behind the row's last DMA piece");
+    static_assert(RING == 6 && 2 * SLOT_BYTES < 65536, "two lane-address sets of three slots each");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 ks_lds_read(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
 
 __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(const ConvParams p)
 {
@@ -678,18 +695,19 @@ __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(c
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wave & 1;          // which half of the reduction this wave owns
+    const int kh = wave & 1;          // which half of the reduction this wave owns = the output tile it finishes
     const int pg = wave >> 1;         // which 32-pixel group of the row
     const int hl = lane >> 5, pl = lane & 31;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
+    // local tile 0 = the tile this wave finishes (global tile kh), local tile 1 = the partner's
     bf16x8 wreg[9][C::KCW][C::NCT];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int j = 0; j < C::KCW; ++j)
 #pragma unroll
-            for (int ct = 0; ct < C::NCT; ++ct) wreg[t][j][ct] = p.wpack[((t * 6 + 3 * kh + j) * 2 + ct) * 64 + lane];
+            for (int lt = 0; lt < C::NCT; ++lt) wreg[t][j][lt] = p.wpack[((t * 6 + 3 * kh + j) * 2 + (kh ^ lt)) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
     }
     static_for<0, 9 * C::KCW * C::NCT>([&](auto f_c) {   // the loads land before the row loop, not between its MFMAs
@@ -698,28 +716,29 @@ __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(c
         asm volatile("" : "+a"(wreg[f / (C::KCW * C::NCT)][(f / C::NCT) % C::KCW][f % C::NCT]));
     });
 
-    // store-time lane roles: lane = (pixel st_q of a group of 8 pixels, 8-channel chunk st_c); this wave finishes store
-    // groups 2 kh and 2 kh + 1 of its pixel group from both waves' partials
-    const int st_q = lane >> 3, st_c = lane & 7;
-    const unsigned stage0 = lds_base + (unsigned)C::STAGE_OFF;
-    // own staging area of parity 0 / the pair's two areas (k half 0 first: the sum is formed in one order everywhere)
-    const unsigned wst = stage0 + (unsigned)(wave * C::STAGE_BYTES) + (unsigned)(pl * C::PXS) + (unsigned)(((hl ^ (pl & 15)) & 15) << 4);
-    unsigned rda[2], rdb[2];
+    // staging of one tile: pixel-major, 8 slots of 4 channels, slot index XOR-swizzled by the pixel
+    const unsigned stage_px = (unsigned)(pl * C::PXS) + (unsigned)(((hl ^ ((pl >> 1) & 7)) & 7) << 4);   // quad g: ^ (2g << 4)
+    const unsigned w_give = lds_base + (unsigned)C::GIVE_OFF + (unsigned)(wave * C::TILE_BYTES) + stage_px;          // + parity
+    const unsigned w_own = lds_base + (unsigned)C::OWN_OFF + (unsigned)(wave * C::TILE_BYTES) + stage_px;
+    // store-time lane roles: lane = (pixel st_q of a group of 16 pixels, 8-channel chunk st_c of the tile)
+    const int st_q = lane >> 2, st_c = lane & 3;
+    unsigned r_own[2], r_got[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int q = (2 * kh + g) * 8 + st_q;
-        const unsigned off = (unsigned)(q * C::PXS) + (unsigned)((((2 * st_c) ^ (q & 15)) & 15) << 4);
-        rda[g] = stage0 + (unsigned)((2 * pg) * C::STAGE_BYTES) + off;
-        rdb[g] = stage0 + (unsigned)((2 * pg + 1) * C::STAGE_BYTES) + off;
+    for (int k = 0; k < 2; ++k) {
+        const int q = k * 16 + st_q;
+        const unsigned off = (unsigned)(q * C::PXS) + (unsigned)((((2 * st_c) ^ ((q >> 1) & 7)) & 7) << 4);
+        r_own[k] = lds_base + (unsigned)C::OWN_OFF + (unsigned)(wave * C::TILE_BYTES) + off;
+        r_got[k] = lds_base + (unsigned)C::GIVE_OFF + (unsigned)((wave ^ 1) * C::TILE_BYTES) + off;                  // + parity
     }
     float breg[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const int co = st_c * 8 + r;
+        const int co = kh * 32 + st_c * 8 + r;
         breg[r] = ((p.bias != nullptr && co < p.cout) ? p.bias[co] : 0.0f) * p.alpha;
     }
-    // fragment j of tap column kx: k-chunk 3 kh + j = (sub-image, chunk pair) of LDS pixel 32 pg + pl + kx
-    unsigned rdk[3][C::KCW];
+    // fragment j of tap column kx: k-chunk 3 kh + j = (sub-image, chunk pair) of LDS pixel 32 pg + pl + kx; set 0 is
+    // based at ring slot 0, set 1 at slot 3
+    unsigned rdk[2][3][C::KCW];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int px = 32 * pg + pl + kx;
@@ -730,7 +749,8 @@ __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(c
             const int cpp = sub ? L::cpp(1) : L::cpp(0), lc = sub ? L::lcpp(1) : L::lcpp(0);
             const int f = (px >> (4 - lc)) & (cpp - 1);
             const unsigned off = (unsigned)((sub ? L::sub_off(1) : 0) + px * cpp * 16 + ((hl ^ f) << 4));
-            rdk[kx][j] = lds_base + (off ^ (unsigned)(kcl << 5));
+            rdk[0][kx][j] = lds_base + (off ^ (unsigned)(kcl << 5));
+            rdk[1][kx][j] = rdk[0][kx][j] + 3u * (unsigned)C::SLOT_BYTES;
         }
     }
 
@@ -738,7 +758,7 @@ __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(c
     const int csrc0 = p.ca_stride, csrc1 = p.cb;
     bf16x8 bq[2][C::KCW];
     f32x16 acc[C::NCT];
-    f32x4 ea[2][2], eb[2][2];   // [store group of this wave][lo / hi]: k half 0's and k half 1's partial
+    f32x4 ea[2][2], eb[2][2];   // [store group][lo / hi]: k half 0's and k half 1's partial (one summation order everywhere)
     float ev[8];
 
     const int item_stride = p.main_items == p.total_items ? (int)gridDim.x
@@ -790,12 +810,12 @@ __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(c
         }
         unsigned vox[2];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int xq = x0 + 32 * pg + (2 * kh + g) * 8 + st_q;
-            vox[g] = (xq < W && st_c * 8 < p.cout_w) ? (unsigned)((xq * p.cout_stride + st_c * 8) * 2) : kOobOffset;
+        for (int k = 0; k < 2; ++k) {
+            const int xq = x0 + 32 * pg + k * 16 + st_q;
+            const int ch = kh * 32 + st_c * 8;
+            vox[k] = (xq < W && ch < p.cout_w) ? (unsigned)((xq * p.cout_stride + ch) * 2) : kOobOffset;
         }
 
-        int ring_pos = 0;
         auto issue_piece = [&](auto m_c, const unsigned soff0, const unsigned soff1, const unsigned slot_off) {
             constexpr int m = decltype(m_c)::value;
             const int q = wave + m * C::NWAVES;
@@ -812,112 +832,120 @@ __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(c
             soff0 = yin ? pix * (unsigned)(csrc0 * 2) : kOobOffset;
             soff1 = yin ? pix * (unsigned)(csrc1 * 2) : kOobOffset;
         };
-        // epilogue of store group g (0 / 1 of this wave) of the row staged with parity SP
-        auto epi_read = [&](auto g_c, const unsigned par_off) {
-            constexpr int g = decltype(g_c)::value;
-            ea[g][0] = lds_read_f32x4(rda[g] + par_off);
-            ea[g][1] = lds_read_f32x4((rda[g] + par_off) ^ 16u);
-            eb[g][0] = lds_read_f32x4(rdb[g] + par_off);
-            eb[g][1] = lds_read_f32x4((rdb[g] + par_off) ^ 16u);
+        // epilogue of store group k of the row whose partner partial was staged with parity offset par_off
+        auto epi_read = [&](auto k_c, const unsigned par_off) {
+            constexpr int k = decltype(k_c)::value;
+            // [a] = k half 0's partial, [b] = k half 1's: the own one for kh == 0, the partner's otherwise
+            const unsigned a0 = kh == 0 ? r_own[k] : r_got[k] + par_off;
+            const unsigned b0 = kh == 0 ? r_got[k] + par_off : r_own[k];
+            ea[k][0] = lds_read_f32x4(a0);
+            ea[k][1] = lds_read_f32x4(a0 ^ 16u);
+            eb[k][0] = lds_read_f32x4(b0);
+            eb[k][1] = lds_read_f32x4(b0 ^ 16u);
         };
-        auto epi_fence = [&](auto g_c) {
+        auto epi_fence = [&](auto k_c) {
             SRHIP_CAPTURE(ea); SRHIP_CAPTURE(eb);
-            constexpr int g = decltype(g_c)::value;
-            SRHIP_LOAD_FENCE(ea[g][0]); SRHIP_LOAD_FENCE(ea[g][1]); SRHIP_LOAD_FENCE(eb[g][0]); SRHIP_LOAD_FENCE(eb[g][1]);
+            constexpr int k = decltype(k_c)::value;
+            SRHIP_LOAD_FENCE(ea[k][0]); SRHIP_LOAD_FENCE(ea[k][1]); SRHIP_LOAD_FENCE(eb[k][0]); SRHIP_LOAD_FENCE(eb[k][1]);
         };
-        auto epi_elem = [&](auto g_c, auto e_c) {
-            constexpr int g = decltype(g_c)::value;
+        auto epi_elem = [&](auto k_c, auto e_c) {
+            constexpr int k = decltype(k_c)::value;
             constexpr int e = decltype(e_c)::value;
-            const float x = ea[g][e >> 2][e & 3] + eb[g][e >> 2][e & 3];
+            const float x = ea[k][e >> 2][e & 3] + eb[k][e >> 2][e & 3];
             const float t = fmaf(x, p.alpha, breg[e]);
             ev[e] = fmaxf(t, t * p.slope);
         };
-        auto epi_store = [&](auto g_c, const unsigned store_soff) {
-            constexpr int g = decltype(g_c)::value;
+        auto epi_store = [&](auto k_c, const unsigned store_soff) {
+            constexpr int k = decltype(k_c)::value;
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(ev[2 * e], ev[2 * e + 1]);
-            buffer_store_b128_guarded(o, dst_srd, vox[g], store_soff);
+            buffer_store_b128_guarded(o, dst_srd, vox[k], store_soff);
         };
 
-        auto row_body = [&](auto par_c, const int i) {
-            constexpr int PAR = decltype(par_c)::value;
+        // One output row; Q = i mod RING fixes the ring slots of input rows i .. i+2 and the row parity.
+        auto row_body = [&](auto q_c, const int i) {
+            constexpr int Q = decltype(q_c)::value;
+            constexpr int PAR = Q & 1;
             if (i == 0) vm_wait<0>();
             else if (i < C::LA - 2) vm_wait<C::WAIT_EARLY>();
             else vm_wait<C::WAIT_STEADY>();
-            lds_wait<0>();   // this wave's staged partial of row i-1 is complete before its partner is told so
+            lds_wait<0>();   // the partial this wave staged for its partner in the previous row is complete before the barrier says so
             __builtin_amdgcn_s_barrier();
 
             const int y = y0 + i;
             unsigned dma_s0, dma_s1;
             row_soff(i + C::LA, dma_s0, dma_s1);
-            const unsigned dma_slot = (unsigned)((ring_pos == 0 ? C::RING - 1 : ring_pos - 1) * C::SLOT_BYTES);
+            constexpr unsigned dma_slot = (unsigned)(((Q + C::LA) % C::RING) * C::SLOT_BYTES);
             const unsigned st_soff = i > 0 ? (unsigned)(y - 1) * out_pitch : kOobOffset;   // stores of row i-1
-            const unsigned prev_stage = (unsigned)((PAR ^ 1) * C::NWAVES * C::STAGE_BYTES);  // where row i-1 was staged
-            unsigned rowa[3];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int sl = ring_pos + ky;
-                rowa[ky] = (unsigned)((sl >= C::RING ? sl - C::RING : sl) * C::SLOT_BYTES);
-            }
-            ring_pos = (ring_pos + 1 == C::RING) ? 0 : ring_pos + 1;
+            constexpr unsigned prev_par = (unsigned)((PAR ^ 1) * C::NWAVES * C::TILE_BYTES);  // where the partner staged row i-1
+            constexpr unsigned own_par = (unsigned)(PAR * C::NWAVES * C::TILE_BYTES);
 
-            if constexpr (PAR == 0) {
-                if (i == 0) {
-                    static_for<0, C::KCW>([&](auto j_c) {
-                        constexpr int j = decltype(j_c)::value;
-                        bq[0][j] = lds_read_b128(rowa[0] + rdk[0][j]);
-                    });
+            auto frag = [&](auto slot_c, auto kx_c, auto j_c) {
+                constexpr int sl = decltype(slot_c)::value % C::RING;
+                return ks_lds_read<(sl % 3) * C::SLOT_BYTES>(rdk[sl / 3][decltype(kx_c)::value][decltype(j_c)::value]);
+            };
+            if constexpr (Q == 0) {
+                if (i == 0) {   // first row of the item: nobody fetched its tap 0 yet
+                    static_for<0, C::KCW>([&](auto j_c) { bq[0][decltype(j_c)::value] = frag(IntC<0>{}, IntC<0>{}, j_c); });
                     lds_wait<0>();
                     static_for<0, C::KCW>([&](auto j_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[0][decltype(j_c)::value]); });
                 }
             }
 
-            // tap t of row i: 6 MFMAs; gap 0 carries the staging reads of a store group of row i-1 (taps 0 and 4),
-            // gaps 1..3 the three fragments of the next tap; between them the previous row's epilogue arithmetic
-            // (group 0 in taps 1..3, stored in tap 4; group 1 in taps 5..7, stored in tap 8) and the LDS-DMA pieces of
-            // row i+LA (taps 0..MAXP-1)
+            // Schedule of the row (previous row = i - 1):
+            //   tap 0   tile-major, partner's tile first; gaps 1, 2: the previous row's OWN-tile accumulator -> staging
+            //           (before MFMA 3 starts to overwrite it)
+            //   tap 1 / tap 4, gap 0    staging reads of store group 0 / 1 of the previous row (own partial + partner's)
+            //   taps 2..4 / 5..7        its arithmetic (elements {0,1,2}, {3,4,5}, {6,7} in gaps 3..5); stores in taps 4 (gap 5) / 8
+            //   tap 8   tile-major, partner's tile first; gaps 4, 5: that tile's accumulator -> the partner's staging area
+            //   taps 0..MAXP-1, last gap   LDS-DMA piece of row i + LA
             static_for<0, 9>([&](auto t_c) {
                 SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(ea); SRHIP_CAPTURE(eb); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(wreg);
                 constexpr int t = decltype(t_c)::value;
                 constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
                 constexpr int tn = (t + 1) % 9;
                 constexpr int kyn = (t == 8) ? 1 : (t + 1) / 3;
+                constexpr bool TILE_MAJOR = t == 0 || t == 8;
                 lds_wait<0>();
-                if constexpr (t == 1) epi_fence(IntC<0>{});
+                if constexpr (t == 2) epi_fence(IntC<0>{});
                 if constexpr (t == 5) epi_fence(IntC<1>{});
                 static_for<0, C::KCW>([&](auto j_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(j_c)::value]); });
                 static_for<0, C::MPT>([&](auto m_c) {
                     SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(ea); SRHIP_CAPTURE(eb); SRHIP_CAPTURE(ev); SRHIP_CAPTURE(wreg);
                     constexpr int ml = decltype(m_c)::value;
-                    constexpr int j = ml / C::NCT, ct = ml % C::NCT;
-                    mfma_pinned<true, (t == 0 && j == 0), ct>(acc[ct], wreg[t][j][ct], bq[cur][j]);
-                    if constexpr (ml == 0 && t == 0) epi_read(IntC<0 * ml>{}, prev_stage);
-                    if constexpr (ml == 0 && t == 4) epi_read(IntC<1 + 0 * ml>{}, prev_stage);
+                    constexpr int j = TILE_MAJOR ? ml % C::KCW : ml / C::NCT;
+                    constexpr int lt = TILE_MAJOR ? 1 - ml / C::KCW : ml % C::NCT;
+                    mfma_pinned<true, (t == 0 && j == 0), lt>(acc[lt], wreg[t][j][lt], bq[cur][j]);
+                    if constexpr (ml == 0 && t == 1) epi_read(IntC<0 * ml>{}, prev_par);
+                    if constexpr (ml == 0 && t == 4) epi_read(IntC<1 + 0 * ml>{}, prev_par);
                     if constexpr (ml >= 1 && ml <= C::KCW) {
                         constexpr int jr = ml - 1;
-                        bq[nxt][jr] = lds_read_b128(rowa[kyn] + rdk[tn % 3][jr]);
+                        bq[nxt][jr] = frag(IntC<Q + kyn>{}, IntC<tn % 3>{}, IntC<jr>{});
                     }
-                    // epilogue arithmetic of row i-1: taps 1..3 / 5..7 take elements {0,1,2}, {3,4,5}, {6,7} in gaps 3..5
-                    if constexpr ((t >= 1 && t <= 3) || (t >= 5 && t <= 7)) {
+                    if constexpr (t == 0 && (ml == 1 || ml == 2)) {   // own tile of the previous row (behind this tap's reads)
+                        lds_write_acc_quad<0, 2 * (ml - 1)>(w_own ^ (unsigned)((4 * (ml - 1)) << 4), acc[0]);
+                        lds_write_acc_quad<0, 2 * (ml - 1) + 1>(w_own ^ (unsigned)((4 * (ml - 1) + 2) << 4), acc[0]);
+                    }
+                    if constexpr (t == 8 && (ml == 4 || ml == 5)) {   // the partner's tile of this row
+                        lds_write_acc_quad<1, 2 * (ml - 4)>((w_give + own_par) ^ (unsigned)((4 * (ml - 4)) << 4), acc[1]);
+                        lds_write_acc_quad<1, 2 * (ml - 4) + 1>((w_give + own_par) ^ (unsigned)((4 * (ml - 4) + 2) << 4), acc[1]);
+                    }
+                    if constexpr ((t >= 2 && t <= 4) || (t >= 5 && t <= 7)) {
                         constexpr int G = t >= 5 ? 1 : 0;
-                        constexpr int e = 3 * ((t - 1) & 3) + (ml - 3);
-                        if constexpr (ml >= 3 && e < 8 && e < 3 * ((t - 1) & 3) + 3) epi_elem(IntC<G + 0 * ml>{}, IntC<e>{});
+                        constexpr int e0 = 3 * (t - (G ? 5 : 2));
+                        constexpr int e = e0 + (ml - 3);
+                        // group 0's last elements share tap 4 with group 1's reads; its store closes that tap
+                        if constexpr (ml >= 3 && e < 8 && !(G == 0 && t == 4 && ml == 5)) epi_elem(IntC<G + 0 * ml>{}, IntC<e>{});
                     }
-                    if constexpr (t == 4 && ml == 4) epi_store(IntC<0 * ml>{}, st_soff);
-                    if constexpr (t == 8 && ml == 4) epi_store(IntC<1 + 0 * ml>{}, st_soff);
+                    if constexpr (t == 4 && ml == 5) epi_store(IntC<0 * ml>{}, st_soff);
+                    if constexpr (t == 8 && ml == 2) epi_store(IntC<1 + 0 * ml>{}, st_soff);
                     if constexpr (t < C::MAXP && ml == 5) issue_piece(IntC<t + 0 * ml>{}, dma_s0, dma_s1, dma_slot);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
-            asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]), "+" SRHIP_ACC_REG1(acc[1]));
-            constexpr unsigned own_stage = (unsigned)(PAR * C::NWAVES * C::STAGE_BYTES);
-            static_for<0, 4 * C::NCT>([&](auto s_c) {
-                constexpr int S = decltype(s_c)::value;
-                constexpr int ct = S / 4, g = S % 4;
-                lds_write_acc_quad<ct, g>((wst + own_stage) ^ (unsigned)((ct * 8 + 2 * g) << 4), acc[ct]);
-            });
-            lds_wait<4 * C::NCT>();   // tap 8's fragments of the next row's tap 0 (older than the staging writes)
+            // in flight across the end of the row: tap 8's four staging writes, issued behind its fragment reads
+            lds_wait<4>();
             static_for<0, C::KCW>([&](auto j_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(j_c)::value]); });
         };
 
@@ -928,24 +956,31 @@ __global__ __launch_bounds__(KsCfg::NWAVES * 64, 1) void conv3x3_ksplit_kernel(c
             row_soff(r, s0, s1);
             static_for<0, C::MAXP>([&](auto m_c) { issue_piece(m_c, s0, s1, (unsigned)(r * C::SLOT_BYTES)); });
         }
-        ring_pos = 0;
 #pragma unroll 1
-        for (int i = 0; i < nout; i += 2) {
-            row_body(IntC<0>{}, i);
-            if (i + 1 < nout) row_body(IntC<1>{}, i + 1);
+        for (int i = 0; i < nout; i += C::RING) {
+            static_for<0, C::RING>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+                if (Q == 0 || i + Q < nout) row_body(q_c, i + Q);
+            });
         }
-        // drain: the last row's partials meet
+        // drain: the last row's own tile goes to the staging area (no next row does it), the partials meet
+        asm volatile("s_nop 15\n\ts_nop 3" : "+" SRHIP_ACC_REG0(acc[0]));
+        static_for<0, 4>([&](auto g_c) {
+            SRHIP_CAPTURE(acc);
+            constexpr int g = decltype(g_c)::value;
+            lds_write_acc_quad<0, g>(w_own ^ (unsigned)((2 * g) << 4), acc[0]);
+        });
         lds_wait<0>();
         __builtin_amdgcn_s_barrier();
         {
             const unsigned st_soff = (unsigned)(y1 - 1) * out_pitch;
-            const unsigned last_stage = (unsigned)(((nout - 1) & 1) * C::NWAVES * C::STAGE_BYTES);
-            static_for<0, 2>([&](auto g_c) {
-                epi_read(g_c, last_stage);
+            const unsigned last_par = (unsigned)(((nout - 1) & 1) * C::NWAVES * C::TILE_BYTES);
+            static_for<0, 2>([&](auto k_c) {
+                epi_read(k_c, last_par);
                 lds_wait<0>();
-                epi_fence(g_c);
-                static_for<0, 8>([&](auto e_c) { epi_elem(g_c, e_c); });
-                epi_store(g_c, st_soff);
+                epi_fence(k_c);
+                static_for<0, 8>([&](auto e_c) { epi_elem(k_c, e_c); });
+                epi_store(k_c, st_soff);
             });
         }
     }
