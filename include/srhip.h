@@ -151,7 +151,18 @@ typedef struct {
     int cout2;            /* 0 or 64: the form above.  1..32: HEAD form for the network's last two layers
                              (core/models/model.py:111-115): wpack2 / bias2 hold a 64 -> cout2 layer, there is no residual,
                              dst = alpha * act2(conv2(relu(conv1(src) + bias1)) + bias2) as fp32 NCHW (n, cout2, h, w) */
+    /* The ReLU pattern of `mid` as 1 bit per element (srhip_conv3x3_pair_bits_bytes() bytes, a layout private to this
+     * entry point), for the backward pass of SRResidualBlock (core/models/model.py:22-33 under core/trainer.py:160; forms
+     * with act2 none that also write `mid`):
+     *   mid_bits_mode 1: also WRITE the bits of mid > 0 (the forward launch of a training step);
+     *   mid_bits_mode 2: instead of the ReLU, zero `mid` where the bit is clear.  With transpose_flip packs of conv2 / conv1
+     *                    as wpack1 / wpack2, src = dL/d(out), bias1 = bias2 = NULL and alpha = the block's scale this launch
+     *                    is the block's data gradient:  mid = conv2^T(src) * [mid_fwd > 0]  (written: the first layer's
+     *                    weight gradient needs it, scaled by alpha),  dst = alpha * conv1^T(mid) + src = dL/d(in). */
+    void* mid_bits;
+    int mid_bits_mode;
 } srhip_conv3x3_pair_args;
+SRHIP_API size_t srhip_conv3x3_pair_bits_bytes(int n, int h, int w);
 SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -360,7 +360,7 @@ def bf16_round(a):
     return r.view(np.float32).reshape(np.shape(a))
 
 
-def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf16=False, trace=None):
+def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf16=False, trace=None, pair_backward=True):
     """Forward (core/models/model.py:147-175) and the backward ATen's autograd performs for it
     (loss.backward(), core/trainer.py:160): returns (sr, grads) with grads keyed like the state
     dict.  `dsr_fn(sr)` supplies dL/d(sr) (the loss itself is outside this restatement).
@@ -427,9 +427,16 @@ def supersampler_forward_backward(sd, lr_frames, hr_buffers, dsr_fn, emulate_bf1
     for i in reversed(range(6)):
         kb, ka = f"main.conv_main.{i}.blks.2", f"main.conv_main.{i}.blks.0"
         wgrad(ts[i], dx, kb, scale=0.2)
-        g2 = r(np.float32(0.2) * dgrad(dx, kb, ts[i].shape) * (ts[i] > 0))
-        wgrad(xs[i], g2, ka)
-        dx = r(dgrad(g2, ka, xs[i].shape) + dx)
+        if i >= 1 and pair_backward:
+            # one launch carries both data gradients: the map between them is stored UNSCALED and the block's 0.2
+            # multiplies the fp32 results behind it (weight gradient, data gradient) instead
+            g2 = r(dgrad(dx, kb, ts[i].shape) * (ts[i] > 0))
+            wgrad(xs[i], g2, ka, scale=0.2)
+            dx = r(np.float32(0.2) * dgrad(g2, ka, xs[i].shape) + dx)
+        else:
+            g2 = r(np.float32(0.2) * dgrad(dx, kb, ts[i].shape) * (ts[i] > 0))
+            wgrad(xs[i], g2, ka)
+            dx = r(dgrad(g2, ka, xs[i].shape) + dx)
     dz = dx * (xs[0] > 0)
     wgrad(cat0, dz, "main.conv_in.0")
     d = dgrad(dz, "main.conv_in.0", cat0.shape)

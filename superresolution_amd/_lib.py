@@ -54,6 +54,7 @@ class Conv3x3PairArgs(ctypes.Structure):
         ("mid", c_void_p), ("dst", c_void_p),
         ("n", c_int), ("h", c_int), ("w", c_int),
         ("act2", c_int), ("slope2", c_float), ("alpha", c_float), ("cout2", c_int),
+        ("mid_bits", c_void_p), ("mid_bits_mode", c_int),
     ]
 
 
@@ -78,6 +79,7 @@ _SIGNATURES = {
                                            c_int, c_int, c_void_p]),
     "srhip_conv3x3_fwd": (c_int, [ctypes.POINTER(Conv3x3Args), c_void_p]),
     "srhip_conv3x3_pair_fwd": (c_int, [ctypes.POINTER(Conv3x3PairArgs), c_void_p]),
+    "srhip_conv3x3_pair_bits_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_conv_gemm_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_conv_gemm_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "srhip_conv_gemm_fwd": (c_int, [ctypes.POINTER(ConvGemmArgs), c_void_p]),

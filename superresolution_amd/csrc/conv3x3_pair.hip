@@ -51,6 +51,7 @@ struct PairParams {
     int range_rows;
     int cout2;   // head form: output channels (1..32) of the second layer, written as fp32 NCHW planes
     int two;     // output columns per strip (the geometry's TWO)
+    char* midbits;   // sign bits of `mid` in first-layer lane order (BITS forms), (n, strip, row, wave, lane) dwords
 };
 
 struct PairCfg {
@@ -76,7 +77,10 @@ struct PairCfg {
     static constexpr int STAGE_OFF = YRING_OFF + YRING_BYTES;
     static constexpr int STAGE_BYTES = 32 * PXS;
     static constexpr int DUMMY_OFF = STAGE_OFF + 2 * STAGE_BYTES;  // 1 KiB sink of the one DMA piece nobody owns
-    static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
+    // sign-bit rows of `mid` (the backward form): four row slots of one dword per first-layer lane
+    static constexpr int BITS_OFF = DUMMY_OFF + 1024;
+    static constexpr int BITS_ROW = NW1 * 256;
+    static constexpr int LDS_BYTES = BITS_OFF + 4 * BITS_ROW;
     static constexpr int NFA1 = 256 / 4;               // first layer: accumulators in VGPRs, 64 fragments in AGPRs
     static constexpr int NFA2 = (256 - 16 * NCT) / 4;  // second layer: accumulators a[0:31], 56 fragments in AGPRs
 };
@@ -185,6 +189,15 @@ __device__ __forceinline__ bf16x8 lds_read_b128_sel(unsigned dyn_off, unsigned a
     else return lds_read_b128(dyn_off + addr);
 }
 
+// `mid` written by the waves that read it: a fragment of the centre tap column is 8 consecutive channels of this lane's
+// own output pixel, so the four fragments of a row are the row's 64 channels (32 contiguous bytes per lane pair).
+template <int OFF>
+__device__ __forceinline__ void store_fragment(const bf16x8& f, const i32x4 srd, unsigned voffset, unsigned soffset)
+{
+    static_assert(OFF >= 0 && OFF < 4096, "buffer instruction offset field is 12 bits");
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 3" ::"v"(f), "v"(voffset), "s"(srd), "s"(soffset), "n"(OFF) : "memory");
+}
+
 struct PairItem {
     int n, x0, y0, nout;
 };
@@ -245,19 +258,31 @@ __device__ __forceinline__ bool pair_iter_next(const PairParams& p, PairIter& i,
 // Waves 0-1: first layer.  Step s computes mid row s (image row y0 - 1 + s) for the 32 columns x0 - 1 + 32 pg + pl from
 // x rows s .. s+2 of the ring; the row's epilogue (accumulators -> bf16 -> LDS) runs between the MFMAs of step s + 1.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool STORE_MID, class P>
+// BITS: how the activation between the two layers is applied.
+//   0  ReLU (forward).
+//   1  ReLU, and the sign pattern of `mid` is also WRITTEN, one dword per lane and row in this wave's accumulator order
+//      (bit j / 16 + j: the even / odd channel of channel pair j of the lane's pixel): 8 bytes per pixel instead of the
+//      128 of the bf16 map, for every row and column the wave computes (halo included; neighbours write equal values).
+//   2  no ReLU: `mid` is zeroed where such a bit is clear.  This is the BACKWARD of the block: with transposed weights,
+//      x = dL/d(out) and the bits of the forward's `mid`, the launch yields conv_a^T((conv_b^T x) * [mid > 0]) * alpha + x.
+// (`mid` itself, when the caller asks for it, is written by the waves that READ it: the second layer's.)
+template <class P, int BITS>
 __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
                                                  const int lane)
 {
     const int hl = lane >> 5, pl = lane & 31;
-    constexpr bool IMM = !STORE_MID;               // compile-time ring slots (see `step`)
-    constexpr int UNR = IMM ? P::RING : 2;         // copies of the row loop's body
-    // vector-memory schedule of one step: taps 0..3 [mid store of row s-2 (STORE_MID)] [DMA piece t of x row s+LA],
-    // tap 4 [DMA piece 4]; the last DMA is the last operation of the step.
-    constexpr int VM_STEP = P::MAXP + (STORE_MID ? 4 : 0);
-    constexpr int WAIT_STEADY = (P::LA - 3) * VM_STEP;                 // row s+2 was issued in step s+2-LA
+    constexpr bool IMM = true;                     // compile-time ring slots (see `step`)
+    constexpr int UNR = P::RING;                   // copies of the row loop's body
+    // vector-memory schedule of one step: [BITS 2: LDS-DMA of the sign-bit dwords of mid row s+2, first] taps 0..MAXP-1
+    // [DMA piece t of x row s+LA] [BITS 1: the sign-bit dword of mid row s-1, tap 7].  The bits a step applies (row s-1)
+    // were fetched three steps earlier, as that step's FIRST operation: MAXP + 2 VM_STEP younger ones, which the wait for
+    // x row s+2 (2 VM_STEP younger ones) covers.  They travel through LDS like the x rows: a register that is the target
+    // of a load in flight cannot be kept out of the compiler's copies across the unrolled loop's back edge.
+    constexpr int VM_STEP = P::MAXP + (BITS != 0 ? 1 : 0);
+    constexpr int WAIT_STEADY = (BITS == 1 ? 1 : 0) + (P::LA - 3) * VM_STEP;   // row s+2 was issued in step s+2-LA
     constexpr int WAIT_EARLY = P::MAXP + VM_STEP < 2 * VM_STEP ? P::MAXP + VM_STEP : 2 * VM_STEP;
     static_assert(WAIT_STEADY <= 63 && P::LA == 5, "vmcnt is a 6-bit field; the early-step waits assume LA = 5");
+    static_assert(BITS == 0 || P::RING % 4 == 0, "the sign-bit rows rotate over four LDS slots");
 
     bf16x8 wreg[9][P::KC][P::NCT];
 #pragma unroll
@@ -298,12 +323,6 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
     // its quad (ct, g) goes to wy ^ ((4 ct + g) << 4) of the row's slot (slot offsets are multiples of 1 KiB: the XOR
     // of bits 4..6 commutes with adding them, so the slot enters through the write's offset field)
     const unsigned wy = lds_base + (unsigned)P::YRING_OFF + (unsigned)(q * 128 + 8 * hl + (((q >> 1) & 7) << 4));
-    unsigned rb[4];  // read-back for the mid store: group k = pixels 32 pg + 8 k + (lane >> 3), chunk lane & 7
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int qk = 32 * pg + 8 * k + (lane >> 3);
-        rb[k] = lds_base + (unsigned)P::YRING_OFF + (unsigned)(qk * 128 + (((lane & 7) ^ ((qk >> 1) & 7)) << 4));
-    }
 
     const int H = p.h, W = p.w;
     bf16x8 bq[2][P::KC];
@@ -314,10 +333,8 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
         for (int ct = 0; ct < P::NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][ct][r] = 0.0f;
-    u32x4 midv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) midv[k] = u32x4{0u, 0u, 0u, 0u};
     unsigned e_p0 = 0, e_p1 = 0, e_addr = 0;
+    unsigned mb = 0u;   // BITS 2: sign bits of the mid row in the epilogue;  BITS 1: collects the bits of that row
 
     PairIter iter = pair_iter_begin(p);
     PairItem it;
@@ -328,7 +345,21 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
         const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
         const __amdgpu_buffer_rsrc_t rsrc_x =
             __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + (long long)it.n * img), 0, (int)img, 0x00020000);
-        const i32x4 mid_srd = make_srd(STORE_MID ? p.mid + (long long)it.n * img : p.dst, STORE_MID ? img : 0u);
+        // sign bits: (n, strip, image row, first-layer wave, lane) dwords
+        const unsigned bits_img = (unsigned)H * (unsigned)(P::NW1 * 256);
+        const i32x4 bits_srd = make_srd(BITS != 0 ? p.midbits + (long long)(it.n * p.nstrips + x0 / P::TWO) * bits_img : p.dst,
+                                        BITS != 0 ? bits_img : 0u);
+        const unsigned bits_vo = (unsigned)((pg * 64 + lane) * 4);
+        auto bits_soff = [&](const int yimg) -> unsigned { return (yimg >= 0 && yimg < H) ? (unsigned)yimg * (unsigned)(P::NW1 * 256) : kOobOffset; };
+        const __amdgpu_buffer_rsrc_t bits_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(BITS == 2 ? p.midbits + (long long)(it.n * p.nstrips + x0 / P::TWO) * bits_img : p.dst), 0,
+            BITS == 2 ? (int)bits_img : 0, 0x00020000);
+        // BITS 2: LDS-DMA of one row's dwords (this wave's 64) into row slot `slot`
+        auto fetch_bits = [&](const int slot, const int yimg) {
+            if constexpr (BITS == 2)
+                lds_dma_b32(bits_rsrc, (__attribute__((address_space(3))) void*)(smem + P::BITS_OFF + slot * P::BITS_ROW + pg * 256),
+                            (int)bits_vo, (int)bits_soff(yimg));
+        };
 
         unsigned poff[P::MAXP];
 #pragma unroll
@@ -343,13 +374,6 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
         }
         const int ycol = x0 - 1 + q;
         const unsigned colmask = (ycol >= 0 && ycol < W) ? 0xffffffffu : 0u;
-        unsigned mvo[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int qk = 32 * pg + 8 * k + (lane >> 3);
-            const int col = x0 - 1 + qk;
-            mvo[k] = (STORE_MID && qk >= 1 && qk <= P::TWO && col < W) ? (unsigned)((col * P::CH + (lane & 7) * 8) * 2) : kOobOffset;
-        }
 
         auto issue_piece = [&](auto m_c, const unsigned soff, const unsigned slot_off) {
             constexpr int m = decltype(m_c)::value;
@@ -363,11 +387,30 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             const bool yin = (y >= 0) & (y < H) & (rx < nin);
             return yin ? (unsigned)y * row_pitch : kOobOffset;
         };
-        // epilogue of one accumulator quad: four consecutive channels of this lane's pixel -> bf16, ReLU, padding mask
-        auto quad_pack = [&](const f32x16& a, auto g_c, const unsigned ymask, unsigned& o0, unsigned& o1) {
-            constexpr int g = decltype(g_c)::value;
-            o0 = relu_bf16x2(pack_bf16x2(a[4 * g + 0], a[4 * g + 1])) & ymask;
-            o1 = relu_bf16x2(pack_bf16x2(a[4 * g + 2], a[4 * g + 3])) & ymask;
+        // epilogue of accumulator quad t = 4 ct + g: four consecutive channels of this lane's pixel (channel pairs 2t and
+        // 2t + 1) -> bf16, ReLU or sign-bit mask, padding mask
+        auto keep = [&](const float v, const unsigned bits, const int pos) -> float {   // v where bit `pos` is set, else 0
+            return __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe((int)bits, pos, 1));
+        };
+        auto pair_lo = [&](const f32x16& a, auto t_c, const unsigned bits) -> unsigned {
+            constexpr int t = decltype(t_c)::value, g = t % 4;
+            if constexpr (BITS == 2) return pack_bf16x2(keep(a[4 * g + 0], bits, 2 * t), keep(a[4 * g + 1], bits, 16 + 2 * t));
+            else return pack_bf16x2(a[4 * g + 0], a[4 * g + 1]);
+        };
+        auto pair_hi = [&](const f32x16& a, auto t_c, const unsigned bits) -> unsigned {
+            constexpr int t = decltype(t_c)::value, g = t % 4;
+            if constexpr (BITS == 2) return pack_bf16x2(keep(a[4 * g + 2], bits, 2 * t + 1), keep(a[4 * g + 3], bits, 16 + 2 * t + 1));
+            else return pack_bf16x2(a[4 * g + 2], a[4 * g + 3]);
+        };
+        auto act_mask = [&](const unsigned v, const unsigned ymask) -> unsigned {
+            if constexpr (BITS == 2) return v & ymask;
+            else return relu_bf16x2(v) & ymask;
+        };
+        // BITS 1: the two flags (value != 0, i.e. > 0 behind the ReLU) of a packed pair, at bits 0 and 16
+        auto flags = [&](const unsigned v) -> unsigned {
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const u16x2 one = {1, 1};
+            return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, v), one));
         };
 
         // IMM (the form that does not store mid): the row loop is unrolled over the x ring, Q = s mod RING, so the slots
@@ -397,26 +440,31 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) rowx[ky] = IMM ? 0u : (unsigned)(((s + ky) % P::RING) * P::SLOT_BYTES);
             const unsigned ymask = (s >= 1 && yimg >= 0 && yimg < H) ? colmask : 0u;
-            // mid row s-2 (read back at the end of step s-1) goes to HBM if it is one of the segment's own rows
-            const int mr = s - 2;
-            const unsigned mid_soff = (mr >= 1 && mr <= nout) ? (unsigned)(y0 - 1 + mr) * row_pitch : kOobOffset;
+            if constexpr (BITS == 2) {
+                // the sign bits of mid row s-1 (landed: see the schedule above; the last row's after a full drain)
+                if (compute || s == nout + 2) {
+                    if (!compute) vm_wait<0>();
+                    mb = lds_read_b32_off<((Q + 3) & 3) * P::BITS_ROW>(lds_base + (unsigned)(P::BITS_OFF + pg * 256 + lane * 4));
+                }
+            }
 
             if (!compute) {
                 if (s == nout + 2) {
-                    // the last mid row's epilogue and the last mid store, with nothing to hide them behind
+                    // the last mid row's epilogue, with nothing to hide it behind
+                    if constexpr (BITS == 2) {
+                        lds_wait<0>();
+                        SRHIP_LOAD_FENCE(mb);
+                    }
                     static_for<0, 8>([&](auto t_c) {
-                        SRHIP_CAPTURE(acc);
+                        SRHIP_CAPTURE(acc); SRHIP_CAPTURE(mb);
                         constexpr int t = decltype(t_c)::value;
-                        unsigned o0, o1;
-                        quad_pack(acc[PAR ^ 1][t / 4], IntC<t % 4>{}, ymask, o0, o1);
+                        const unsigned o0 = act_mask(pair_lo(acc[PAR ^ 1][t / 4], t_c, mb), ymask);
+                        const unsigned o1 = act_mask(pair_hi(acc[PAR ^ 1][t / 4], t_c, mb), ymask);
+                        if constexpr (BITS == 1) mb = (t == 0 ? 0u : mb) | (flags(o0) << (2 * t)) | (flags(o1) << (2 * t + 1));
                         lds_write_b64_off<YSLOT>(xor_slot16<4 * (t / 4) + (t % 4), IMM>(wys), o0, o1);
                     });
-                    if constexpr (STORE_MID) {
-                        static_for<0, 4>([&](auto k_c) {
-                            SRHIP_CAPTURE(midv);
-                            buffer_store_b128_guarded(midv[decltype(k_c)::value], mid_srd, mvo[decltype(k_c)::value], mid_soff);
-                        });
-                    }
+                    if constexpr (BITS == 1)
+                        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(mb), "v"(bits_vo), "s"(bits_srd), "s"(bits_soff(yimg)) : "memory");
                     lds_wait<0>();
                 }
                 return;
@@ -437,7 +485,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             }
 
             static_for<0, 9>([&](auto t_c) {
-                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(midv); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(mb); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
                 SRHIP_CAPTURE(e_p0); SRHIP_CAPTURE(e_p1); SRHIP_CAPTURE(e_addr);
                 constexpr int t = decltype(t_c)::value;
                 constexpr int cur = (PAR + t) & 1, nxt = cur ^ 1;
@@ -448,8 +496,9 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                 if constexpr (t >= 1) lds_wait<1>();
                 else lds_wait<0>();
                 static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[cur][decltype(kc_c)::value]); });
+                if constexpr (BITS == 2 && t == 0) SRHIP_LOAD_FENCE(mb);
                 static_for<0, P::MPT>([&](auto m_c) {
-                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(midv); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
+                    SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(mb); SRHIP_CAPTURE(wreg); SRHIP_CAPTURE(biasv);
                     SRHIP_CAPTURE(e_p0); SRHIP_CAPTURE(e_p1); SRHIP_CAPTURE(e_addr);
                     constexpr int ml = decltype(m_c)::value;
                     constexpr int kc = ml / P::NCT, ct = ml % P::NCT;
@@ -460,21 +509,23 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
                         constexpr int kr = ml - 1;
                         bq[nxt][kr] = lds_read_b128_sel<IMM, ((Q + kyn) % P::RING) * P::SLOT_BYTES>(rowx[kyn], rd[tn % 3][kr]);
                     }
+                    // BITS 2: this step's first vector-memory operation fetches the sign bits of mid row s+2 (used in step s+3)
+                    if constexpr (BITS == 2 && t == 0 && ml == 0) fetch_bits((Q + 2) & 3, yimg + 3);
                     // taps 0..7: quad t of the previous row's accumulators -> mid ring
                     if constexpr (t < 8) {
                         constexpr int qct = t / 4, qg = t % 4;
-                        if constexpr (ml == 0) e_p0 = pack_bf16x2(acc[PAR ^ 1][qct][4 * qg + 0], acc[PAR ^ 1][qct][4 * qg + 1]);
-                        if constexpr (ml == 1) e_p1 = pack_bf16x2(acc[PAR ^ 1][qct][4 * qg + 2], acc[PAR ^ 1][qct][4 * qg + 3]);
-                        if constexpr (ml == 2) e_p0 = relu_bf16x2(e_p0) & ymask;
-                        if constexpr (ml == 3) e_p1 = relu_bf16x2(e_p1) & ymask;
+                        if constexpr (ml == 0) e_p0 = pair_lo(acc[PAR ^ 1][qct], IntC<t + 0 * ml>{}, mb);
+                        if constexpr (ml == 1) e_p1 = pair_hi(acc[PAR ^ 1][qct], IntC<t + 0 * ml>{}, mb);
+                        if constexpr (ml == 2) e_p0 = act_mask(e_p0, ymask);
+                        if constexpr (ml == 3) e_p1 = act_mask(e_p1, ymask);
+                        if constexpr (BITS == 1 && ml == 4) mb = (t == 0 ? 0u : mb) | (flags(e_p0) << (2 * t)) | (flags(e_p1) << (2 * t + 1));
                         if constexpr (ml == 5) e_addr = xor_slot16<4 * qct + qg, IMM>(wys);
                         if constexpr (ml == 7) lds_write_b64_off<YSLOT>(e_addr, e_p0, e_p1);
                     }
-                    if constexpr (STORE_MID && t < 4 && ml == 5)
-                        buffer_store_b128_guarded(midv[t], mid_srd, mvo[t], mid_soff);
                     if constexpr (t < P::MAXP && ml == 6) issue_piece(IntC<t + 0 * ml>{}, dma_soff, dma_slot);
-                    // tap 8: read the finished mid row (this wave's 32 pixels) back pixel-major for the store in the next step
-                    if constexpr (STORE_MID && t == 8 && ml >= 4) midv[ml - 4] = lds_read_u32x4_off<YSLOT>(yslot_dyn + rb[ml - 4]);
+                    // BITS 1: the finished row's sign bits (behind the step's last DMA piece: WAIT_STEADY counts it)
+                    if constexpr (BITS == 1 && t == 7 && ml == 6)
+                        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(mb), "v"(bits_vo), "s"(bits_srd), "s"(bits_soff(s >= 1 ? yimg : -1)) : "memory");
                     __builtin_amdgcn_sched_barrier(0);  // keep the interleave as written
                 });
             });
@@ -483,7 +534,6 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             // nothing stays in flight across the end of a step: next row's tap-0 fragments, the read-back, the mid writes
             lds_wait<0>();
             static_for<0, P::KC>([&](auto kc_c) { SRHIP_CAPTURE(bq); SRHIP_LOAD_FENCE(bq[PAR ^ 1][decltype(kc_c)::value]); });
-            if constexpr (STORE_MID) static_for<0, 4>([&](auto k_c) { SRHIP_CAPTURE(midv); SRHIP_LOAD_FENCE(midv[decltype(k_c)::value]); });
         };
 
         __builtin_amdgcn_s_barrier();  // every wave is done with the previous item's LDS rows
@@ -492,18 +542,16 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
             const unsigned so = row_soff(r);
             static_for<0, P::MAXP>([&](auto m_c) { issue_piece(m_c, so, (unsigned)(r * P::SLOT_BYTES)); });
         }
+        // the sign bits of mid rows 0 and 1 (image rows y0 - 1, y0): step 0 waits for everything issued so far
+        fetch_bits(0, y0 - 1);
+        fetch_bits(1, y0);
         const int nsteps = nout + P::LAG;
 #pragma unroll 1
         for (int s = 0; s < nsteps; s += UNR) {
-            if constexpr (UNR == 2) {
-                step(IntC<0>{}, s);
-                if (s + 1 < nsteps) step(IntC<1>{}, s + 1);
-            } else {
-                static_for<0, UNR>([&](auto q_c) {
-                    constexpr int Q = decltype(q_c)::value;
-                    if (Q == 0 || s + Q < nsteps) step(q_c, s + Q);
-                });
-            }
+            static_for<0, UNR>([&](auto q_c) {
+                constexpr int Q = decltype(q_c)::value;
+                if (Q == 0 || s + Q < nsteps) step(q_c, s + Q);
+            });
         }
     }
 }
@@ -514,7 +562,7 @@ __device__ __forceinline__ void pair_first_layer(const PairParams& p, char* smem
 // ------------------------------------------------------------------------------------------------------------------
 // ACT2: activation of the second layer known at compile time (0 none, 1 ReLU, 2 LeakyReLU): its epilogue is the wave's
 // critical vector-ALU work, and the common forms need fewer instructions than max(t, slope * t).
-template <int ACT2>
+template <int ACT2, bool STORE_MID>
 __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
                                                   const int lane)
 {
@@ -583,6 +631,10 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
         const unsigned img = (unsigned)(H * W) * (unsigned)(P::CH * 2);
         const unsigned row_pitch = (unsigned)W * (unsigned)(P::CH * 2);
         const i32x4 dst_srd = make_srd(p.dst + (long long)it.n * img, img);
+        // STORE_MID: tap 4's fragments are mid row o + 1 = the output row's own image row, pixel = this lane's output column
+        const i32x4 mid_srd = make_srd(STORE_MID ? p.mid + (long long)it.n * img : p.dst, STORE_MID ? img : 0u);
+        const int mcol = x0 + 32 * pg + pl;
+        const unsigned mvo = (STORE_MID && 32 * pg + pl < P::TWO && mcol < W) ? (unsigned)((mcol * P::CH + hl * 8) * 2) : kOobOffset;
         unsigned vox[P::NST];
 #pragma unroll
         for (int k = 0; k < P::NST; ++k) {
@@ -680,6 +732,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
                         bq[nxt][kr] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kr]);
                     }
                     // accumulator quads -> staging (behind the tap's LDS reads: the end-of-row wait counts on that)
+                    if constexpr (STORE_MID && t == 4 && (ml & 1)) store_fragment<(ml / 2) * 32>(bq[cur][ml / 2], mid_srd, mvo, (unsigned)y * row_pitch);
                     if constexpr (t == 0 && ml < 4) lds_write_acc_quad<1, ml>(wst ^ (unsigned)((8 + 2 * ml) << 4), acc[1]);
                     if constexpr (t == 8 && ml >= 4) lds_write_acc_quad<0, ml - 4>(wst ^ (unsigned)((2 * (ml - 4)) << 4), acc[0]);
                     static_for<ml * NS / P::MPT, (ml + 1) * NS / P::MPT>([&](auto s_c) {
@@ -752,7 +805,7 @@ __device__ __forceinline__ void pair_second_layer(const PairParams& p, char* sme
 // layer alone costs, and the 64-channel map between the two layers never reaches memory.  Same barrier sequence, mid-ring
 // addressing and fragment pipeline as pair_second_layer; the epilogue goes straight from the accumulator to 4-byte plane
 // stores (lane = pixel: 128 contiguous bytes per half-wave and channel).
-template <int ACT2>
+template <int ACT2, bool STORE_MID>
 __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem, const unsigned lds_base, const int pg,
                                                 const int lane)
 {
@@ -799,6 +852,9 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
             (void*)(p.dst + (long long)it.n * p.cout2 * plane), 0, (int)((unsigned)p.cout2 * plane), 0x00020000);
         const int jq = 32 * pg + pl, xq = x0 + jq;   // output column within the strip / the image
         const bool col_ok = jq < P::TWO && xq < W;
+        const unsigned mimg = (unsigned)(H * W) * (unsigned)(P::CH * 2);
+        const i32x4 mid_srd = make_srd(STORE_MID ? p.mid + (long long)it.n * mimg : p.dst, STORE_MID ? mimg : 0u);
+        const unsigned mvo = (STORE_MID && col_ok) ? (unsigned)((xq * P::CH + hl * 8) * 2) : kOobOffset;
 
         auto row_body = [&](auto q_c, const int o) {
             constexpr int Q = decltype(q_c)::value;   // o mod NY: compile-time mid-ring slots, as in pair_second_layer
@@ -826,6 +882,7 @@ __device__ __forceinline__ void pair_head_layer(const PairParams& p, char* smem,
                     SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wreg);
                     constexpr int kc = decltype(kc_c)::value;
                     mfma_pinned<true, (t == 0 && kc == 0), 0>(acc, wreg[t][kc], bq[cur][kc]);
+                    if constexpr (STORE_MID && t == 4) store_fragment<kc * 32>(bq[cur][kc], mid_srd, mvo, (unsigned)(y * W) * (unsigned)(P::CH * 2));
                     bq[nxt][kc] = lds_read_b128_off<((Q + kyn) & (P::NY - 1)) * P::SLOT_BYTES>(rd[tn % 3][kc]);   // fragment kc of the next tap
                 });
             });
@@ -880,7 +937,7 @@ __device__ __forceinline__ void mfma_vv(f32x16& acc, const bf16x8& w, const bf16
 //     out[r-2] = S1 + R[dy 2] (+ bias, activation, alpha -> stored),   S1 <- S0 + R[dy 1],   S0 <- R[dy 0].
 // Rows of `mid` outside the image are zeros in the ring, so the vertical padding needs nothing here.  Accumulator
 // register 4 dy + e of lane (pl, hl) is channel 4 hl + e of pixel pl.
-template <int ACT2, class P>
+template <int ACT2, bool STORE_MID, class P>
 __device__ __forceinline__ void pair_head3_layer(const PairParams& p, char* smem, const unsigned lds_base, const int lane)
 {
     constexpr int NG = P::NW1;
@@ -934,11 +991,14 @@ __device__ __forceinline__ void pair_head3_layer(const PairParams& p, char* smem
         const unsigned plane = (unsigned)(H * W) * 4u;
         const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.dst + (long long)it.n * p.cout2 * plane), 0, (int)((unsigned)p.cout2 * plane), 0x00020000);
-        unsigned vo[NG][4];
+        const unsigned mimg = (unsigned)(H * W) * (unsigned)(P::CH * 2);
+        const i32x4 mid_srd = make_srd(STORE_MID ? p.mid + (long long)it.n * mimg : p.dst, STORE_MID ? mimg : 0u);
+        unsigned vo[NG][4], mvo[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int jq = 32 * g + pl, xq = x0 + jq;
             const bool col_ok = jq < P::TWO && xq < W;
+            mvo[g] = (STORE_MID && col_ok) ? (unsigned)((xq * P::CH + hl * 8) * 2) : kOobOffset;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 vo[g][e] = (col_ok && 4 * hl + e < p.cout2) ? (unsigned)(4 * hl + e) * plane + (unsigned)xq * 4u : kOobOffset;
@@ -949,12 +1009,14 @@ __device__ __forceinline__ void pair_head3_layer(const PairParams& p, char* smem
             constexpr int SLOT = ((Q + 2 * P::NY - 2) % P::NY) * P::SLOT_BYTES;
             const int o = r - 2;                                        // the output row this mid row completes
             const unsigned soff = (o >= 0 && o < nout) ? (unsigned)((y0 + o) * W) * 4u : kOobOffset;
+            // STORE_MID: the centre column's fragments of mid row r are image row y0 - 1 + r, this lane's output column
+            const unsigned msoff = (r >= 1 && r <= nout) ? (unsigned)((y0 - 1 + r) * W) * (unsigned)(P::CH * 2) : kOobOffset;
             static_for<0, P::KC>([&](auto kc_c) {
                 constexpr int kc = decltype(kc_c)::value;
                 bq[0][kc] = lds_read_b128_off<SLOT>(rd[0][kc]);
             });
             static_for<0, 3 * NG>([&](auto st_c) {
-                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wh); SRHIP_CAPTURE(s0); SRHIP_CAPTURE(s1); SRHIP_CAPTURE(vo);
+                SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wh); SRHIP_CAPTURE(s0); SRHIP_CAPTURE(s1); SRHIP_CAPTURE(vo); SRHIP_CAPTURE(mvo);
                 constexpr int st = decltype(st_c)::value;
                 constexpr int g = st / 3, dx = st % 3;
                 constexpr int cur = st & 1, nxt = cur ^ 1;
@@ -965,6 +1027,7 @@ __device__ __forceinline__ void pair_head3_layer(const PairParams& p, char* smem
                     SRHIP_CAPTURE(bq); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(wh);
                     constexpr int kc = decltype(kc_c)::value;
                     mfma_vv<(dx == 0 && kc == 0)>(acc, wh[dx][kc], bq[cur][kc]);
+                    if constexpr (STORE_MID && dx == 1) store_fragment<kc * 32>(bq[cur][kc], mid_srd, mvo[g], msoff);
                     if constexpr (st + 1 < 3 * NG) bq[nxt][kc] = lds_read_b128_off<SLOT + gn * 4096>(rd[dxn][kc]);
                 });
                 if constexpr (dx == 2) {
@@ -998,8 +1061,9 @@ __device__ __forceinline__ void pair_head3_layer(const PairParams& p, char* smem
     }
 }
 
-// HEAD: 0 the residual pair, 1 the head form with two waves per layer (cout2 <= 32), 2 HEAD3 (cout2 <= 8)
-template <bool STORE_MID, int ACT2, int HEAD = 0>
+// HEAD: 0 the residual pair, 1 the head form with two waves per layer (cout2 <= 32), 2 HEAD3 (cout2 <= 8); BITS: sign bits
+// of `mid` written (1) or applied instead of the ReLU (2), see pair_first_layer
+template <bool STORE_MID, int ACT2, int HEAD = 0, int BITS = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1007,17 +1071,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_pair_kernel(const PairParams p
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // (`mid`, when asked for, is written by the waves of the second layer)
     if constexpr (HEAD == 2) {
-        if (wave < HeadCfg::NW1) pair_first_layer<STORE_MID, HeadCfg>(p, smem, lds_base, wave, lane);
-        else pair_head3_layer<ACT2, HeadCfg>(p, smem, lds_base, lane);
+        if (wave < HeadCfg::NW1) pair_first_layer<HeadCfg, BITS>(p, smem, lds_base, wave, lane);
+        else pair_head3_layer<ACT2, STORE_MID, HeadCfg>(p, smem, lds_base, lane);
     } else {
-        if (wave < 2) pair_first_layer<STORE_MID, PairCfg>(p, smem, lds_base, wave, lane);
-        else if constexpr (HEAD == 1) pair_head_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
-        else pair_second_layer<ACT2>(p, smem, lds_base, wave - 2, lane);
+        if (wave < 2) pair_first_layer<PairCfg, BITS>(p, smem, lds_base, wave, lane);
+        else if constexpr (HEAD == 1) pair_head_layer<ACT2, STORE_MID>(p, smem, lds_base, wave - 2, lane);
+        else pair_second_layer<ACT2, STORE_MID>(p, smem, lds_base, wave - 2, lane);
     }
 }
 
-template <bool STORE_MID, int ACT2, int HEAD = 0>
+template <bool STORE_MID, int ACT2, int HEAD = 0, int BITS = 0>
 int launch_pair(PairParams p, hipStream_t stream)
 {
     using P = std::conditional_t<HEAD == 2, HeadCfg, PairCfg>;
@@ -1025,7 +1090,7 @@ int launch_pair(PairParams p, hipStream_t stream)
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];  // per device
     const int dev = srhip_current_device();
     if (!configured_dev[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)conv3x3_pair_kernel<STORE_MID, ACT2, HEAD, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 P::LDS_BYTES) != hipSuccess) {
             srhip_set_error("conv3x3_pair: cannot raise the dynamic LDS limit to %d", P::LDS_BYTES);
             return SRHIP_ERR_LAUNCH;
@@ -1095,13 +1160,19 @@ int launch_pair(PairParams p, hipStream_t stream)
             }
         }
     }
-    hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2, HEAD>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv3x3_pair_kernel<STORE_MID, ACT2, HEAD, BITS>), dim3(grid), dim3(256), P::LDS_BYTES, stream, p);
     return srhip_check_launch("conv3x3_pair_kernel");
 }
 
 }  // namespace
 
 extern "C" {
+
+SRHIP_API size_t srhip_conv3x3_pair_bits_bytes(int n, int h, int w)
+{
+    if (n < 1 || h < 1 || w < 1) return 0;
+    return (size_t)n * srhip_div_up(w, PairCfg::TWO) * h * (PairCfg::NW1 * 256);
+}
 
 SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* a, void* stream)
 {
@@ -1125,19 +1196,27 @@ SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* a, void* str
     p.slope2 = a->act2 == SRHIP_ACT_NONE ? 1.0f : (a->act2 == SRHIP_ACT_RELU ? 0.0f : a->slope2);
     p.alpha = a->alpha;
     p.cout2 = a->cout2;
+    p.midbits = (char*)a->mid_bits;
     hipStream_t s = (hipStream_t)stream;
+    if (a->mid_bits_mode != 0) {
+        SRHIP_REQUIRE(a->mid_bits_mode == 1 || a->mid_bits_mode == 2, "conv3x3_pair: mid_bits_mode must be 0, 1 (write) or 2 (apply)");
+        SRHIP_REQUIRE(a->mid_bits != nullptr, "conv3x3_pair: mid_bits_mode %d needs the sign-bit tensor `mid_bits`", a->mid_bits_mode);
+        SRHIP_REQUIRE((a->cout2 == 0 || a->cout2 == 64) && a->act2 == SRHIP_ACT_NONE && a->mid != nullptr,
+                      "conv3x3_pair: the sign-bit forms are built for the SRResidualBlock pair that also stores `mid` (act2 none)");
+        SRHIP_REQUIRE(a->mid_bits_mode == 1 || a->bias1 == nullptr, "conv3x3_pair: the form that applies sign bits takes no first-layer bias");
+        SRHIP_REQUIRE((long long)a->h * 512 < (1ll << 31), "conv3x3_pair: sign-bit rows too long for 32-bit offsets");
+        return a->mid_bits_mode == 1 ? launch_pair<true, 0, 0, 1>(p, s) : launch_pair<true, 0, 0, 2>(p, s);
+    }
     if (a->cout2 != 0 && a->cout2 != 64) {
         SRHIP_REQUIRE(a->cout2 >= 1 && a->cout2 <= 32, "conv3x3_pair: cout2 must be 64 (or 0) or, for the head form, 1..32");
         SRHIP_REQUIRE((long long)a->h * a->w * a->cout2 * 4 < (1ll << 31), "conv3x3_pair: head output too large for 32-bit offsets");
         // up to 8 output channels: three first-layer waves and one wave for the narrow layer (SRHIP_PAIR_HEAD=2 in the
         // environment keeps the two-plus-two form for A/B timing)
         static const bool head3 = []() { const char* e = getenv("SRHIP_PAIR_HEAD"); return !(e && e[0] == '2'); }();
-        // (the form that also stores `mid` keeps two waves per layer: with the store path's registers the three-wave
-        // first layer spills, and spill traffic would break its hand-counted vector-memory waits)
-        if (a->cout2 <= 8 && head3 && a->mid == nullptr) {
-            if (a->act2 == SRHIP_ACT_NONE) return launch_pair<false, 0, 2>(p, s);
-            if (a->act2 == SRHIP_ACT_RELU) return launch_pair<false, 1, 2>(p, s);
-            return launch_pair<false, 2, 2>(p, s);
+        if (a->cout2 <= 8 && head3) {
+            if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0, 2>(p, s) : launch_pair<false, 0, 2>(p, s);
+            if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1, 2>(p, s) : launch_pair<false, 1, 2>(p, s);
+            return a->mid != nullptr ? launch_pair<true, 2, 2>(p, s) : launch_pair<false, 2, 2>(p, s);
         }
         if (a->act2 == SRHIP_ACT_NONE) return a->mid != nullptr ? launch_pair<true, 0, 1>(p, s) : launch_pair<false, 0, 1>(p, s);
         if (a->act2 == SRHIP_ACT_RELU) return a->mid != nullptr ? launch_pair<true, 1, 1>(p, s) : launch_pair<false, 1, 1>(p, s);

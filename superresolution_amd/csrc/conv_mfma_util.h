@@ -101,6 +101,20 @@ __device__ __forceinline__ void lds_dma_b128(__amdgpu_buffer_rsrc_t rsrc, __attr
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 0);
 }
 
+__device__ __forceinline__ void lds_dma_b32(__amdgpu_buffer_rsrc_t rsrc, __attribute__((address_space(3))) void* dst,
+                                            int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 4, voffset, soffset, 0, 0);   // lane l's dword lands at dst + 4 l
+}
+// one dword from LDS, completion left to the caller's lgkmcnt wait and fence
+template <int OFF>
+__device__ __forceinline__ unsigned lds_read_b32_off(const unsigned addr)
+{
+    unsigned r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+
 __device__ __forceinline__ u32x4 buffer_load_b128_async(const i32x4 srd, unsigned voffset, unsigned soffset)
 {
     u32x4 r;

@@ -197,9 +197,14 @@ def signbits_unpack(bits: torch.Tensor, w: int) -> torch.Tensor:
 
 def conv3x3_pair(x: torch.Tensor, wpack1: torch.Tensor, bias1: Optional[torch.Tensor], wpack2: torch.Tensor,
                  bias2: Optional[torch.Tensor], act2: int = ACT_NONE, slope2: float = 0.0, alpha: float = 1.0,
-                 keep_mid: bool = False, out: Optional[torch.Tensor] = None):
+                 keep_mid: bool = False, out: Optional[torch.Tensor] = None, emit_bits: bool = False,
+                 apply_bits: Optional[torch.Tensor] = None):
     """alpha * act2(conv2(relu(conv1(x) + b1)) + b2) + x for a 64-channel NHWC bf16 map in ONE launch (the
-    intermediate map stays in LDS).  ``keep_mid=True`` also returns relu(conv1(x) + b1) (the backward pass needs it)."""
+    intermediate map stays in LDS).  ``keep_mid=True`` also returns relu(conv1(x) + b1) (the backward pass needs it).
+    ``emit_bits=True`` (with keep_mid, act2 none): also returns the intermediate map's ReLU pattern as a bit tensor.
+    ``apply_bits=bits``: the intermediate map is conv1(x) zeroed where the bit is clear instead of relu(conv1(x) + b1) --
+    with transposed / flipped packs of a block's second and first layer this launch is the block's data gradient
+    (returns (dL/d(in), masked gradient of the intermediate map))."""
     x = _req(x, torch.bfloat16, "x")
     if x.dim() != 4 or x.shape[-1] != 64:
         raise ValueError("conv3x3_pair: expected an (N,H,W,64) map")
@@ -212,10 +217,25 @@ def conv3x3_pair(x: torch.Tensor, wpack1: torch.Tensor, bias1: Optional[torch.Te
         out = torch.empty_like(x)
     elif out.shape != x.shape or out.dtype != torch.bfloat16 or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
         raise ValueError("conv3x3_pair: out must be a contiguous bf16 tensor of x's shape, distinct from x")
+    bits, mode = None, 0
+    if emit_bits or apply_bits is not None:
+        if emit_bits and apply_bits is not None:
+            raise ValueError("conv3x3_pair: emit_bits and apply_bits exclude each other")
+        nbytes = lib.srhip_conv3x3_pair_bits_bytes(n, h, w)
+        if emit_bits:
+            bits, mode = torch.empty((nbytes,), dtype=torch.uint8, device=x.device), 1
+        else:
+            bits, mode = _req(apply_bits, torch.uint8, "apply_bits"), 2
+            if bits.numel() != nbytes:
+                raise ValueError("conv3x3_pair: apply_bits does not belong to a map of this shape")
+        keep_mid = True
     mid = torch.empty_like(x) if keep_mid else None
     a = Conv3x3PairArgs(src=x.data_ptr(), wpack1=wpack1.data_ptr(), bias1=_ptr(bias1), wpack2=wpack2.data_ptr(), bias2=_ptr(bias2),
-                        mid=_ptr(mid), dst=out.data_ptr(), n=n, h=h, w=w, act2=act2, slope2=slope2, alpha=alpha)
+                        mid=_ptr(mid), dst=out.data_ptr(), n=n, h=h, w=w, act2=act2, slope2=slope2, alpha=alpha,
+                        mid_bits=_ptr(bits), mid_bits_mode=mode)
     check(lib.srhip_conv3x3_pair_fwd(a, _stream()))
+    if emit_bits:
+        return out, mid, bits
     return (out, mid) if keep_mid else out
 
 

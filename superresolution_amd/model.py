@@ -134,17 +134,37 @@ class SuperSampler(nn.Module):
                           out_nchw_f32=out_nchw_f32, aux_mode=aux_mode)
 
     def _pair(self, name: str, conv_a: nn.Conv2d, conv_b: nn.Conv2d, x: Tensor, act2: int, alpha: float,
-              keep_mid: bool = False):
+              keep_mid: bool = False, emit_bits: bool = False):
         """alpha * act2(conv_b(relu(conv_a(x)))) + x as one launch (the intermediate map stays in LDS);
-        SRHIP_NO_PAIR=1 in the environment runs the two single-layer launches instead (A/B timing)."""
+        SRHIP_NO_PAIR=1 in the environment runs the two single-layer launches instead (A/B timing).
+        ``emit_bits`` (training): returns (out, mid, bits) with the ReLU pattern of ``mid`` in the form
+        ``_pair_backward`` reads, or bits = None where the one-launch form does not apply."""
         ch = x.shape[-1]
         if self.use_pair_kernel and ch == 64 and conv_a.out_channels == 64 and conv_b.out_channels == 64:
             wa, wb = self._pack(name + "a", conv_a, ch, ch), self._pack(name + "b", conv_b, ch, ch)
-            return F_.conv3x3_pair(x, wa, conv_a.bias.detach(), wb, conv_b.bias.detach(), act2=act2, alpha=alpha,
-                                   keep_mid=keep_mid)
+            if emit_bits and act2 == F_.ACT_NONE and os.environ.get("SRHIP_NO_PAIR_BWD", "0") != "1":
+                return F_.conv3x3_pair(x, wa, conv_a.bias.detach(), wb, conv_b.bias.detach(), act2=act2, alpha=alpha,
+                                       emit_bits=True)
+            res = F_.conv3x3_pair(x, wa, conv_a.bias.detach(), wb, conv_b.bias.detach(), act2=act2, alpha=alpha,
+                                  keep_mid=keep_mid or emit_bits)
+            return res + (None,) if emit_bits else res
         t = self._conv(name + "a", conv_a, x, ch)
         out = self._conv(name + "b", conv_b, t, ch, res=x, act=act2, alpha=alpha)
+        if emit_bits:
+            return out, t, None
         return (out, t) if keep_mid else out
+
+    def _pair_backward(self, name: str, conv_a: nn.Conv2d, conv_b: nn.Conv2d, dz: Tensor, bits: Tensor, alpha: float):
+        """Both data gradients of the block out = x + alpha * conv_b(relu(conv_a(x))) as one launch: from dz = dL/d(out)
+        and the ReLU pattern the forward launch emitted, returns (dL/dx, g) with g = conv_b^T(dz) * [mid > 0], the
+        gradient of conv_a's output WITHOUT the factor alpha (the caller scales the weight gradient formed from it)."""
+        ch = dz.shape[-1]
+        packs = []
+        for tag, conv in (("b", conv_b), ("a", conv_a)):
+            w = conv.weight
+            packs.append(self._cached_pack(f"{name}{tag}^T0", w, lambda w=w: F_.conv3x3_pack_weights(
+                w.detach(), conv.out_channels, ch, cout=conv.in_channels, cout_off=0, transpose_flip=True)))
+        return F_.conv3x3_pair(dz, packs[0], None, packs[1], None, act2=F_.ACT_NONE, alpha=alpha, apply_bits=bits)
 
     def _pair_head(self, name: str, conv_a: nn.Conv2d, conv_b: nn.Conv2d, x: Tensor, keep_mid: bool = False):
         """conv_b(relu(conv_a(x))) as fp32 NCHW, the network's last two layers (model.py:111-115), as one launch when

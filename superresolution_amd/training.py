@@ -90,15 +90,21 @@ class _SuperSamplerFn(torch.autograd.Function):
         # the two-source launch cannot emit its ReLU pattern itself: one light pass (reads the map, writes 1/16 of it)
         # lets the backward mask inside the last data-gradient launch of the trunk
         x0bits = F_.signbits_from_map(xs[0]) if (bits and sr == 64) else None
-        ts = []
+        ts, tbits = [], []
         for i, blk in enumerate(m.main.conv_main):
-            # one launch per block; the intermediate map is written out as well (the backward needs it)
-            x_next, t = m._pair(f"m{i}", blk.blks[0], blk.blks[2], xs[-1], F_.ACT_NONE, 0.2, keep_mid=True)
+            # one launch per block; the intermediate map is written out as well (the backward needs it), and from the
+            # second block on its ReLU pattern too, in the form the block's one-launch backward reads (the first
+            # block's backward folds conv_in's ReLU into its last launch instead and keeps two launches)
+            if i >= 1:
+                x_next, t, tb = m._pair(f"m{i}", blk.blks[0], blk.blks[2], xs[-1], F_.ACT_NONE, 0.2, emit_bits=True)
+            else:
+                (x_next, t), tb = m._pair(f"m{i}", blk.blks[0], blk.blks[2], xs[-1], F_.ACT_NONE, 0.2, keep_mid=True), None
             ts.append(t)
+            tbits.append(tb)
             xs.append(x_next)
         a = m._conv("after", m.after_main[0], up, fr, xb=xs[-1], cin_b=sr)
         out, c0 = m._pair_head("fin", m.final_conv[0], m.final_conv[2], a, keep_mid=True)   # one launch, c0 kept for the backward
-        sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]), bits=bits, x0bits=x0bits)
+        sv.update(f=f, up=up, gb=gb, g=g, xs=xs, ts=ts, tbits=tbits, a=a, c0=c0, lr_hw=tuple(lr.shape[-2:]), bits=bits, x0bits=x0bits)
         ctx.model, ctx.sv = m, sv
         return out
 
@@ -133,6 +139,10 @@ class _SuperSamplerFn(torch.autograd.Function):
         for i in reversed(range(len(m.main.conv_main))):
             blk = m.main.conv_main[i].blks
             _wgrad(ts[i], dx, blk[2], grads, sr, scale=0.2, red=red)
+            if sv["tbits"][i] is not None:   # both data gradients in one launch; the map between them carries no 0.2
+                dx, g2 = m._pair_backward(f"m{i}", blk[0], blk[2], dx, sv["tbits"][i], 0.2)
+                _wgrad(xs[i], g2, blk[0], grads, sr, scale=0.2, red=red)
+                continue
             g2 = dgrad(f"m{i}b", blk[2], dx, alpha=0.2, mask=ts[i])
             _wgrad(xs[i], g2, blk[0], grads, sr, red=red)
             if i == 0 and sv["x0bits"] is not None:   # ... and the ReLU of conv_in applied to the fan-in sum, same launch

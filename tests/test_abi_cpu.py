@@ -121,7 +121,7 @@ def test_every_args_struct_matches_the_header_field_for_field():
         assert ctypes.sizeof(cls) == size, cname
         for fld, off in offs.items():
             assert getattr(cls, fld).offset == off, (cname, fld)
-    assert ctypes.sizeof(_lib.Conv3x3Args) == 128 and ctypes.sizeof(_lib.Conv3x3PairArgs) == 88
+    assert ctypes.sizeof(_lib.Conv3x3Args) == 128 and ctypes.sizeof(_lib.Conv3x3PairArgs) == 104
     assert ctypes.sizeof(_lib.ConvGemmArgs) == 136
 
 

@@ -214,3 +214,58 @@ def test_pair_work_partitions(F_, shape, kind):
     dm = (mid.float() - t.float()).abs()
     assert float(dm.max()) <= 2.0 ** -7 * max(1.0, float(t.float().abs().max())) and float((dm > 0).float().mean()) <= 0.02, kind
     assert bool(torch.isfinite(out.float()).all())
+
+
+@pytest.mark.parametrize("shape", [(1, 20, 70), (2, 37, 130), (1, 5, 3), (1, 9, 125), (1, 64, 62), (3, 1, 1), (1, 70, 190)])
+def test_pair_sign_bits_forward_and_block_data_gradient(F_, shape):
+    """SRResidualBlock under training (core/models/model.py:22-33, core/trainer.py:160).  Forward: the launch that keeps
+    `mid` also writes its ReLU pattern as one bit per element -- outputs unchanged.  Backward: ONE launch on transposed /
+    flipped packs, dL/d(out) and those bits gives the masked gradient of `mid` and dL/d(in); both equal, bit for bit, the
+    two single-layer launches it replaces (data gradient of the second layer masked by the stored `mid`, data gradient
+    of the first layer scaled by 0.2 plus the skip path)."""
+    n, h, w = shape
+    x, w1, b1, w2, b2 = _case(900 * h + w + n, n, h, w)
+    xc = x.cuda()
+    wp1, wp2 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64), F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    out0, mid0 = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=F_.ACT_NONE, alpha=0.2, keep_mid=True)
+    out, mid, bits = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=F_.ACT_NONE, alpha=0.2, emit_bits=True)
+    assert torch.equal(out, out0) and torch.equal(mid, mid0)
+    g = torch.Generator().manual_seed(h * 7 + w)
+    dz = (torch.rand(n, h, w, 64, generator=g) - 0.5).to(torch.bfloat16).cuda()
+    wtb = F_.conv3x3_pack_weights(w2.cuda(), 64, 64, transpose_flip=True)
+    wta = F_.conv3x3_pack_weights(w1.cuda(), 64, 64, transpose_flip=True)
+    dx, g2 = F_.conv3x3_pair(dz, wtb, None, wta, None, act2=F_.ACT_NONE, alpha=0.2, apply_bits=bits)
+    g2_ref = F_.conv3x3(dz, wtb, None, 64, res=mid, act=F_.ACT_NONE, res_mode=F_.RES_MASK)
+    dx_ref = F_.conv3x3(g2_ref, wta, None, 64, res=dz, act=F_.ACT_NONE, alpha=0.2)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dx.float()).all())
+    assert torch.equal(g2, g2_ref), float((g2.float() - g2_ref.float()).abs().max())
+    assert torch.equal(dx, dx_ref), float((dx.float() - dx_ref.float()).abs().max())
+    # against the oracle's statement of the same two products
+    from oracle import oracle as orc
+    dzn = dz.float().permute(0, 3, 1, 2).cpu().numpy()
+    midn = mid.float().permute(0, 3, 1, 2).cpu().numpy()
+    g2o = orc.conv2d_bwd_input(dzn, w2.numpy(), midn.shape, padding=1) * (midn > 0)
+    assert np.abs(g2.float().permute(0, 3, 1, 2).cpu().numpy() - g2o).max() <= 2e-2
+
+
+def test_pair_sign_bits_full_size(F_):
+    """The training shape (range partition, 17 strips x 16 images) and 4K (two-class partition): bits written by one
+    partition's segments are read by the backward launch's, halo rows and columns included."""
+    _, w1, b1, w2, b2 = _case(3, 1, 8, 8)
+    wp1, wp2 = F_.conv3x3_pack_weights(w1.cuda(), 64, 64), F_.conv3x3_pack_weights(w2.cuda(), 64, 64)
+    wtb = F_.conv3x3_pack_weights(w2.cuda(), 64, 64, transpose_flip=True)
+    wta = F_.conv3x3_pack_weights(w1.cuda(), 64, 64, transpose_flip=True)
+    for n, h, w in ((16, 1024, 1024), (1, 2160, 3840)):
+        g = torch.Generator(device="cuda").manual_seed(h + n)
+        xc = (torch.rand(n, h, w, 64, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+        dz = (torch.rand(n, h, w, 64, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+        out, mid, bits = F_.conv3x3_pair(xc, wp1, b1.cuda(), wp2, b2.cuda(), act2=F_.ACT_NONE, alpha=0.2, emit_bits=True)
+        dx, g2 = F_.conv3x3_pair(dz, wtb, None, wta, None, act2=F_.ACT_NONE, alpha=0.2, apply_bits=bits)
+        g2_ref = F_.conv3x3(dz, wtb, None, 64, res=mid, act=F_.ACT_NONE, res_mode=F_.RES_MASK)
+        assert torch.equal(g2, g2_ref), (n, h, w)
+        del g2
+        dx_ref = F_.conv3x3(g2_ref, wta, None, 64, res=dz, act=F_.ACT_NONE, alpha=0.2)
+        assert torch.equal(dx, dx_ref), (n, h, w)
+        del xc, dz, out, mid, bits, dx, g2_ref, dx_ref
+        torch.cuda.empty_cache()
