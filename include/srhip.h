@@ -298,6 +298,16 @@ SRHIP_API int srhip_max_pool2d_nhwc(const void* src, void* dst, int n, int c, in
 SRHIP_API int srhip_resize_bilinear_nhwc(const void* src, const void* addend, void* dst, int n, int c,
                                          int h, int w, int ho, int wo, int align_corners, void* stream);
 SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst, size_t count, void* stream);
+/* The tail of the ESA block as ONE pass (core/arch/RepRFN.py:303-308, replaces the last four launches of the
+ * layer-by-layer form):  dst = x * sigmoid(conv4(F.interpolate(c3, (h,w), "bilinear", align_corners=False) + conv_f(c1)))
+ *   x, dst (N,h,w,cstride) bf16, cstride = cfeat or 64, the first cfeat channels gated (cfeat in {16,32,48,64}), the others
+ *   copied;  c1 (N,h,w,16) bf16 = conv1(x);
+ *   c3 (N,h3,w3,16) bf16 = conv3(max_pool(conv2(c1)));  wf (16,16), bf (16), w4 (cfeat,16), b4 (cfeat): fp32 1x1 kernels
+ *   (output-major) and biases; the kernels are rounded to bf16 (matrix cores, fp32 accumulation).  conv_f's output, the
+ *   sum and conv4's output are rounded to bf16 where the layer-by-layer form stores them. */
+SRHIP_API int srhip_esa_tail_bf16(const void* x, const void* c1, const void* c3, const float* wf, const float* bf,
+                                  const float* w4, const float* b4, void* dst, int n, int h, int w, int h3, int w3,
+                                  int cfeat, int cstride, void* stream);
 
 /* Fused loss of the default trainer configuration, forward AND backward in one call:
  *   xc   = clamp(sr, clip_min, clip_max)                       (core/trainer.py:154-156)

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "srhip_conv_transpose2x2s2": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
     "srhip_gradient_map_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "srhip_sigmoid_gate_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "srhip_esa_tail_bf16": (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
     "srhip_l1_ssim_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_l1_ssim_loss": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 4 + [c_void_p]),
     "srhip_backward_warp_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

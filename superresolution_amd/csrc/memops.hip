@@ -504,6 +504,54 @@ __global__ void max_pool_nhwc_kernel(const unsigned short* __restrict__ src, uns
         *(uint4*)(dst + (((long long)img * ho + oy) * wo + ox) * c + g * 8) = pack8(m);
     }
 }
+// The same pooling for windows of K <= 8 rows with eight lanes per output: lane (i & 7) takes window row ky = i & 7 (its K
+// loads are independent, so they are all in flight at once; the kernel above walks the k * k taps one after the other and
+// a launch with few outputs -- the ESA branch pools 269 x 479 down to 88 x 158 -- waits k * k memory latencies), then
+// three exchange steps over the eight lanes.  The winner is the same value: max is associative, and any NaN wins.
+template <int K>
+__global__ void max_pool_rows_nhwc_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int n, int c,
+                                          int h, int w, int ho, int wo, int s)
+{
+    static_assert(K <= 8, "one lane per window row");
+    const int cg = c / 8;
+    const long long total = (long long)n * ho * wo * cg * 8;
+    const long long stride = (long long)gridDim.x * blockDim.x;   // a multiple of 8: the eight lanes of an output stay together
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 - (threadIdx.x & 7) < total; i0 += stride) {
+        const bool live = i0 < total;
+        const long long i = live ? i0 : total - 1;
+        const int ky = (int)(i & 7);
+        long long p = i >> 3;
+        const int g = (int)(p % cg); p /= cg;
+        const int ox = (int)(p % wo); p /= wo;
+        const int oy = (int)(p % ho);
+        const int img = (int)(p / ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        if (ky < K) {
+            uint4 t[K];
+            const unsigned short* rp = src + (((long long)img * h + oy * s + ky) * w + ox * s) * c + g * 8;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) t[kx] = *(const uint4*)(rp + (long long)kx * c);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                float v[8];
+                unpack8(t[kx], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > m[e] || v[e] != v[e]) m[e] = v[e];
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float o = __shfl_xor(m[e], d, 8);
+                if (o > m[e] || o != o) m[e] = o;
+            }
+        if (live && ky == 0) *(uint4*)(dst + (((long long)img * ho + oy) * wo + ox) * c + g * 8) = pack8(m);
+    }
+}
 // F.interpolate / nn.Upsample(size=(ho,wo), mode="bilinear", align_corners=align) (+ optional addend of the output shape)
 __global__ void resize_bilinear_nhwc_kernel(const unsigned short* __restrict__ src, const unsigned short* __restrict__ addend,
                                             unsigned short* __restrict__ dst, int n, int c, int h, int w, int ho, int wo, int align)
@@ -554,6 +602,145 @@ __global__ void sigmoid_gate_kernel(const uint4* __restrict__ x, const uint4* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = a[e] * (1.0f / (1.0f + expf(-b[e])));
         dst[i] = pack8(a);
+    }
+}
+// The tail of RepRFN's ESA block in one pass (core/arch/RepRFN.py:303-308):
+//   dst = x * sigmoid(conv4(resize_bilinear(c3 -> h x w, align_corners=False) + conv_f(c1)))
+// conv_f: 1x1 16 -> 16 on the full-resolution map c1, c3: the 16-channel map of the pooled branch (a few thousand pixels:
+// its taps stay in cache), conv4: 1x1 16 -> CF.  A wave takes 32 consecutive pixels per step; both small layers are one
+// matrix instruction per 32 output channels with K = 16:
+//   * lane (pixel l & 31, half hl = l >> 5) loads channels 8 hl .. 8 hl + 7 of c1: the wave's load is 1 KiB contiguous and
+//     already the instruction's pixel operand;
+//   * conv_f's result arrives as channels {4 hl .. 4 hl + 3, 8 + 4 hl .. 8 + 4 hl + 3} of the lane's pixel.  The sum with the
+//     resized branch is formed for exactly those channels and fed to conv4 AS IS: the contraction index of a matrix
+//     instruction may run over the channels in any order as long as both operands agree, so conv4's weight fragment is
+//     gathered in that order and no lane exchange is needed;
+//   * conv4's result: 4 consecutive channels per register quad -> gate, multiply, 8-byte stores.
+// The maps the layer-by-layer composition stores between its launches (conv_f's output, the sum, conv4's output) are
+// rounded to bf16 here at the same points, in registers; the weights are rounded to bf16 like every matrix-core layer's.
+template <int CF, int CS>
+__global__ __launch_bounds__(kThreads) void esa_tail_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ c1,
+                                                           const unsigned short* __restrict__ c3, const float* __restrict__ wf,
+                                                           const float* __restrict__ bf, const float* __restrict__ w4,
+                                                           const float* __restrict__ b4, unsigned short* __restrict__ dst, int n, int h,
+                                                           int w, int h3, int w3)
+{
+    // CS: channels per pixel of x and dst in memory (CF or 64)
+    constexpr int F = 16, NT = (CF + 31) / 32, NPJ = CS * 4 / 64;   // NPJ: 16-byte pieces of x per lane and step
+    static_assert(CS % 16 == 0 && CS >= CF && CS <= 64, "32 pixels of x are a whole number of 1-KiB wave loads");
+    const int lane = threadIdx.x & 63, pl = lane & 31, hl = lane >> 5;
+    const long long total = (long long)n * h * w;
+    const float sy = (float)h3 / (float)h, sx = (float)w3 / (float)w;
+    // channel of contraction index j in conv4's operands: the order conv_f's accumulators come in
+    auto chan = [&](const int j) { return 8 * (j >> 2) + 4 * hl + (j & 3); };
+    bf16x8 wf_frag, w4_frag[NT];
+    float bfv[8], b4v[NT][4][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wf_frag[j] = (short)f32_to_bf16_bits(pl < F ? wf[pl * F + 8 * hl + j] : 0.0f);
+        bfv[j] = bf[chan(j)];
+    }
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const int o = 32 * ct + pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w4_frag[ct][j] = (short)f32_to_bf16_bits(o < CF ? w4[o * F + chan(j)] : 0.0f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 32 * ct + 8 * g + 4 * hl + e;
+                b4v[ct][g][e] = c < CF ? b4[c] : 0.0f;
+            }
+    }
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __shared__ __attribute__((aligned(16))) char stage[kThreads / 64][32 * 64 * 2];   // per wave: 32 pixels x up to 64 channels
+    char* sw = stage[threadIdx.x >> 6];
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long base = wave0 * 32; base < total; base += nwaves * 32) {
+        const long long i = base + pl;
+        const bool live = i < total;
+        const long long ic = live ? i : total - 1;   // lanes past the end repeat the last pixel and store nothing
+        long long p = ic;
+        const int ox = (int)(p % w); p /= w;
+        const int oy = (int)(p % h);
+        const int img = (int)(p / h);
+        // every load of the step is issued before anything waits: x (the wave's 32 pixels are one contiguous piece of
+        // memory, fetched 16 bytes per lane, whole cache lines per instruction), c1, the four taps of c3
+        constexpr long long cbytes = CS * 2;
+        const long long chunk0 = base * cbytes, endb = total * cbytes;
+        uint4 xv4[NPJ];
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+            const long long off = chunk0 + (long long)(j * 64 + lane) * 16;
+            xv4[j] = *(const uint4*)((const char*)x + (off < endb ? off : endb - 16));
+        }
+        const uint4 c1v = *(const uint4*)(c1 + ic * F + 8 * hl);
+        bf16x8 c1_frag;
+        __builtin_memcpy(&c1_frag, &c1v, 16);
+        const f32x16 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf_frag, c1_frag, zero, 0, 0, 0);
+        // the resized pooled branch at this pixel (same arithmetic as resize_bilinear_nhwc_kernel, align_corners = 0)
+        float fy = __fsub_rn(__fmul_rn(sy, (float)oy + 0.5f), 0.5f);
+        float fx = __fsub_rn(__fmul_rn(sx, (float)ox + 0.5f), 0.5f);
+        if (fy < 0.0f) fy = 0.0f;
+        if (fx < 0.0f) fx = 0.0f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h3 - 1 ? 1 : 0), x1 = x0 + (x0 < w3 - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, hy = 1.0f - ly, lx = fx - (float)x0, hx = 1.0f - lx;
+        const unsigned short* ip = c3 + (long long)img * h3 * w3 * F + 4 * hl;
+        float sv[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // channels 8 q + 4 hl .. + 3
+            const uint2 t00 = *(const uint2*)(ip + ((long long)y0 * w3 + x0) * F + 8 * q);
+            const uint2 t01 = *(const uint2*)(ip + ((long long)y0 * w3 + x1) * F + 8 * q);
+            const uint2 t10 = *(const uint2*)(ip + ((long long)y1 * w3 + x0) * F + 8 * q);
+            const uint2 t11 = *(const uint2*)(ip + ((long long)y1 * w3 + x1) * F + 8 * q);
+            const float a[4] = {bf16_lo(t00.x), bf16_hi(t00.x), bf16_lo(t00.y), bf16_hi(t00.y)};
+            const float b[4] = {bf16_lo(t01.x), bf16_hi(t01.x), bf16_lo(t01.y), bf16_hi(t01.y)};
+            const float c[4] = {bf16_lo(t10.x), bf16_hi(t10.x), bf16_lo(t10.y), bf16_hi(t10.y)};
+            const float d[4] = {bf16_lo(t11.x), bf16_hi(t11.x), bf16_lo(t11.y), bf16_hi(t11.y)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float cf = bf16_bits_to_f32(f32_to_bf16_bits(a1[4 * q + e] + bfv[4 * q + e]));
+                sv[4 * q + e] = (hy * (hx * a[e] + lx * b[e]) + ly * (hx * c[e] + lx * d[e])) + cf;
+            }
+        }
+        bf16x8 s_frag;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_frag[j] = (short)f32_to_bf16_bits(sv[j]);
+        // x goes to LDS as it came, is gated in place in the accumulators' (pixel, 4 channels) order, and is copied out the
+        // way it came in.  Only the wave itself touches its piece, so its own in-order LDS queue is all the ordering it needs.
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) *(uint4*)(sw + (j * 64 + lane) * 16) = xv4[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        char* xl = sw + pl * (int)cbytes + 8 * hl;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const f32x16 a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w4_frag[ct], s_frag, zero, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (32 * ct + 8 * g >= CF) continue;
+                const uint2 xv = *(const uint2*)(xl + (32 * ct + 8 * g) * 2);
+                const float xf[4] = {bf16_lo(xv.x), bf16_hi(xv.x), bf16_lo(xv.y), bf16_hi(xv.y)};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gate = bf16_bits_to_f32(f32_to_bf16_bits(a2[4 * g + e] + b4v[ct][g][e]));
+                    o[e] = xf[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-gate));
+                }
+                *(uint2*)(xl + (32 * ct + 8 * g) * 2) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j) {
+            const long long off = chunk0 + (long long)(j * 64 + lane) * 16;
+            if (off < endb) *(uint4*)((char*)dst + off) = *(const uint4*)(sw + (j * 64 + lane) * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 // dst = cur + sigmoid(f_self * g_cross) * fmap + sigmoid(g_self * f_cross) * grad with one gate value per pixel
@@ -2073,6 +2260,11 @@ SRHIP_API int srhip_max_pool2d_nhwc(const void* src, void* dst, int n, int c, in
     SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && k >= 1 && s >= 1 && h >= k && w >= k, "max_pool2d_nhwc: bad shape (c %% 8 == 0, window inside the image)");
     const int ho = (h - k) / s + 1, wo = (w - k) / s + 1;
     const long long work = (long long)n * ho * wo * (c / 8);
+    if (k == 7) {   // the ESA block's window: eight lanes per output
+        hipLaunchKernelGGL(max_pool_rows_nhwc_kernel<7>, dim3(grid_for(work * 8, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                           (const unsigned short*)src, (unsigned short*)dst, n, c, h, w, ho, wo, s);
+        return srhip_check_launch("max_pool2d_nhwc");
+    }
     hipLaunchKernelGGL(max_pool_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const unsigned short*)src, (unsigned short*)dst, n, c, h, w, ho, wo, k, s);
     return srhip_check_launch("max_pool2d_nhwc");
@@ -2087,6 +2279,34 @@ SRHIP_API int srhip_resize_bilinear_nhwc(const void* src, const void* addend, vo
     hipLaunchKernelGGL(resize_bilinear_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const unsigned short*)src, (const unsigned short*)addend, (unsigned short*)dst, n, c, h, w, ho, wo, align_corners);
     return srhip_check_launch("resize_bilinear_nhwc");
+}
+
+SRHIP_API int srhip_esa_tail_bf16(const void* x, const void* c1, const void* c3, const float* wf, const float* bf, const float* w4,
+                                  const float* b4, void* dst, int n, int h, int w, int h3, int w3, int cfeat, int cstride, void* stream)
+{
+    SRHIP_REQUIRE(x && c1 && c3 && wf && bf && w4 && b4 && dst, "esa_tail_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1 && h3 >= 1 && w3 >= 1, "esa_tail_bf16: empty tensor");
+    SRHIP_REQUIRE(cfeat == 16 || cfeat == 32 || cfeat == 48 || cfeat == 64, "esa_tail_bf16: %d feature channels (16, 32, 48 or 64)", cfeat);
+    SRHIP_REQUIRE(cstride == cfeat || cstride == 64, "esa_tail_bf16: channel stride %d (the %d feature channels, or 64)", cstride, cfeat);
+    SRHIP_REQUIRE((size_t)x % 16 == 0 && (size_t)c1 % 16 == 0 && (size_t)c3 % 16 == 0 && (size_t)dst % 16 == 0, "esa_tail_bf16: maps must be 16-byte aligned");
+    const long long work = (long long)n * h * w * 2;   // a wave covers 32 pixels per step
+    const dim3 grid(grid_for(work, srhip_num_cus())), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+#define SRHIP_ESA_TAIL(CF)                                                                                                     \
+    if (cstride == CF)                                                                                                         \
+        hipLaunchKernelGGL((esa_tail_kernel<CF, CF>), grid, block, 0, s, (const unsigned short*)x, (const unsigned short*)c1,  \
+                           (const unsigned short*)c3, wf, bf, w4, b4, (unsigned short*)dst, n, h, w, h3, w3);                  \
+    else                                                                                                                       \
+        hipLaunchKernelGGL((esa_tail_kernel<CF, 64>), grid, block, 0, s, (const unsigned short*)x, (const unsigned short*)c1,  \
+                           (const unsigned short*)c3, wf, bf, w4, b4, (unsigned short*)dst, n, h, w, h3, w3)
+    switch (cfeat) {
+    case 16: SRHIP_ESA_TAIL(16); break;
+    case 32: SRHIP_ESA_TAIL(32); break;
+    case 48: SRHIP_ESA_TAIL(48); break;
+    default: SRHIP_ESA_TAIL(64); break;
+    }
+#undef SRHIP_ESA_TAIL
+    return srhip_check_launch("esa_tail_bf16");
 }
 
 SRHIP_API int srhip_sigmoid_gate_bf16(const void* x, const void* gate, void* dst, size_t count, void* stream)

@@ -616,6 +616,25 @@ def sigmoid_gate(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def esa_tail(x: torch.Tensor, c1: torch.Tensor, c3: torch.Tensor, wf: torch.Tensor, bf: torch.Tensor, w4: torch.Tensor,
+             b4: torch.Tensor, cfeat: int) -> torch.Tensor:
+    """x * sigmoid(conv4(resize_bilinear(c3 -> x's size) + conv_f(c1))) in one pass (core/arch/RepRFN.py:303-308).
+    x (N,h,w,C) bf16 with C >= cfeat, c1 (N,h,w,16), c3 (N,h3,w3,16) bf16; wf (16,16), w4 (cfeat,16) fp32 (1x1 kernels,
+    trailing unit dimensions allowed) and their biases."""
+    x, c1, c3 = _req(x, torch.bfloat16, "x"), _req(c1, torch.bfloat16, "c1"), _req(c3, torch.bfloat16, "c3")
+    wf = _req(wf.reshape(wf.shape[0], -1), torch.float32, "wf")
+    w4 = _req(w4.reshape(w4.shape[0], -1), torch.float32, "w4")
+    bf, b4 = _req(bf, torch.float32, "bf"), _req(b4, torch.float32, "b4")
+    n, h, w, cs = x.shape
+    if c1.shape != (n, h, w, 16) or c3.shape[0] != n or c3.shape[3] != 16 or tuple(wf.shape) != (16, 16) or tuple(w4.shape) != (cfeat, 16) \
+            or bf.numel() != 16 or b4.numel() != cfeat:
+        raise ValueError("esa_tail: c1 (N,h,w,16), c3 (N,h3,w3,16), wf (16,16), w4 (cfeat,16)")
+    out = torch.empty_like(x)   # channels beyond cfeat are copied from x
+    check(lib.srhip_esa_tail_bf16(x.data_ptr(), c1.data_ptr(), c3.data_ptr(), wf.data_ptr(), bf.data_ptr(), w4.data_ptr(),
+                                  b4.data_ptr(), out.data_ptr(), n, h, w, c3.shape[1], c3.shape[2], cfeat, cs, _stream()))
+    return out
+
+
 def l1_ssim_loss(sr: torch.Tensor, target: torch.Tensor, lambda_l1: float, lambda_ssim: float,
                  clip_min: float = float("-inf"), clip_max: float = float("inf")):
     """Fused clip + L1 + SSIM loss and its gradient: returns (out3, dsr) with out3 = [l1, ssim_loss, total]

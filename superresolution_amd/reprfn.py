@@ -16,6 +16,7 @@ With autograd enabled the module runs `forward_train`: the same graph from diffe
 (`autograd_ops.py`), each RepBlock still ONE convolution whose merged kernel is differentiated back to the nine
 branches.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -206,17 +207,33 @@ class ESA(nn.Module):
         f = self.conv1.out_channels
         h, w = x.shape[1:3]
         c1_ = F_.conv2d_auto(x, self.conv1.weight, self.conv1.bias, stride=1, padding=0)      # 1x1 on the MFMA kernel
-        # 3x3 / stride 2 / pad 0 = the stride-1 pad-1 layer (MFMA) at the odd pixels 2o + 1
-        full = F_.conv2d_auto(c1_, self.conv2.weight, self.conv2.bias, stride=1, padding=1)
-        ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
-        c1 = full[:, 1:2 * ho:2, 1:2 * wo:2, :].contiguous()
+        if F_.use_conv_gemm:   # 3x3 / stride 2 / pad 0 on the implicit-GEMM kernel: only the strided outputs are computed
+            c1 = F_.conv2d_auto(c1_, self.conv2.weight, self.conv2.bias, stride=2, padding=0)
+        else:                  # ... or the stride-1 pad-1 layer at the odd pixels 2o + 1 (same sums per output)
+            full = F_.conv2d_auto(c1_, self.conv2.weight, self.conv2.bias, stride=1, padding=1)
+            ho, wo = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+            c1 = full[:, 1:2 * ho:2, 1:2 * wo:2, :].contiguous()
         v_max = F_.max_pool2d_nhwc(c1, 7, 3)
         c3 = F_.conv2d_auto(v_max, self.conv3.weight, self.conv3.bias, stride=1, padding=1)
+        if f == 16 and n_feats in (16, 32, 48, 64) and os.environ.get("SRHIP_NO_ESA_TAIL", "0") != "1":
+            # conv_f, the resize + add, conv4 and the gate as one pass; weights rounded to bf16 as the MFMA layers' are
+            wf, w4 = self._bf16_weights()
+            return F_.esa_tail(x, c1_, c3, wf, self.conv_f.bias.detach(), w4, self.conv4.bias.detach(), n_feats)
         cf = F_.conv2d_auto(c1_, self.conv_f.weight, self.conv_f.bias, stride=1, padding=0)
         s = F_.resize_bilinear_nhwc(c3, h, w, addend=cf)
         c4 = F_.conv2d_auto(s, self.conv4.weight, self.conv4.bias, stride=1, padding=0)
         assert c4.shape[-1] == x.shape[-1]
         return F_.sigmoid_gate(x, c4)
+
+    def _bf16_weights(self):
+        """conv_f's and conv4's kernels rounded to bf16 (kept as fp32), cached until a parameter changes."""
+        tag = tuple((p._version, p.data_ptr()) for p in (self.conv_f.weight, self.conv4.weight))
+        hit = getattr(self, "_tail_cache", None)
+        if hit is None or hit[0] != tag:
+            r = lambda t: t.detach().to(torch.bfloat16).float().reshape(t.shape[0], -1).contiguous()
+            hit = (tag, (r(self.conv_f.weight), r(self.conv4.weight)))
+            object.__setattr__(self, "_tail_cache", hit)
+        return hit[1]
 
 
 def _esa_train(esa: "ESA", x: Tensor, rec=None) -> Tensor:
@@ -282,6 +299,8 @@ class RepRFN(nn.Module):
         for m in self.modules():
             if hasattr(m, "_eq_cache"):
                 object.__setattr__(m, "_eq_cache", None)
+            if hasattr(m, "_tail_cache"):
+                object.__setattr__(m, "_tail_cache", None)
         F_.invalidate_pack_cache()
 
     def _conv(self, key: str, weight: Tensor, bias: Tensor, x: Tensor, cin: int, **kw) -> Tensor:

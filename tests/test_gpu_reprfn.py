@@ -88,3 +88,38 @@ def test_sigmoid_gate(F_):
     got = F_.sigmoid_gate(x, g).float().cpu().numpy()
     ref = x.float().cpu().numpy() / (1.0 + np.exp(-g.float().cpu().numpy()))
     assert np.abs(got - ref).max() <= 2e-2
+
+
+@pytest.mark.parametrize("cfg", [(1, 48, 30, 41, 48), (2, 48, 64, 57, 64), (1, 16, 21, 33, 16), (1, 64, 40, 24, 64), (1, 32, 17, 90, 32)])
+def test_esa_tail_one_pass_vs_oracle_and_layer_by_layer(F_, cfg):
+    """x * sigmoid(conv4(resize(c3) + conv_f(c1))) (core/arch/RepRFN.py:303-308) as one launch: against the oracle's
+    operators on the same bf16 inputs and bf16-rounded weights (<= 2e-2), and against the four launches it replaces
+    (same rounding points; the sums run in another order: a bf16 step of the gate at most)."""
+    n, cf_, h, w, cs = cfg
+    rng = np.random.default_rng(h * 100 + w)
+    h3, w3 = max(1, ((h - 3) // 2 + 1 - 7) // 3 + 1), max(1, ((w - 3) // 2 + 1 - 7) // 3 + 1)
+    x = bf16r(rng.standard_normal((n, cf_, h, w)))
+    c1 = bf16r(rng.standard_normal((n, 16, h, w)))
+    c3 = bf16r(rng.standard_normal((n, 16, h3, w3)))
+    wf, w4 = bf16r(rng.standard_normal((16, 16, 1, 1)) * 0.3), bf16r(rng.standard_normal((cf_, 16, 1, 1)) * 0.3)
+    bf_, b4 = rng.standard_normal(16).astype(np.float32) * 0.1, rng.standard_normal(cf_).astype(np.float32) * 0.1
+    xa = F_.nchw_f32_to_nhwc_bf16(dev(x), cpad=cs)
+    c1a, c3a = F_.nchw_f32_to_nhwc_bf16(dev(c1)), F_.nchw_f32_to_nhwc_bf16(dev(c3))
+    got = F_.esa_tail(xa, c1a, c3a, dev(wf), dev(bf_), dev(w4), dev(b4), cf_)
+    assert got.shape == xa.shape and bool((got[..., cf_:] == 0).all())
+    got_n = F_.nhwc_bf16_to_nchw_f32(got, cf_).cpu().numpy()
+    # oracle, with the maps the layer-by-layer form stores rounded to bf16
+    cfo = bf16r(orc.conv2d(c1, wf, bf_, 1, 0))
+    so = bf16r(orc.resize_bilinear(c3, h, w) + cfo)
+    c4o = bf16r(orc.conv2d(so, w4, b4, 1, 0))
+    ref = x * (np.float32(1.0) / (np.float32(1.0) + np.exp(-c4o, dtype=np.float32)))
+    assert np.abs(got_n - ref).max() <= 2e-2
+    # the four launches
+    cfl = F_.conv2d_auto(c1a, dev(wf), dev(bf_), stride=1, padding=0)
+    sl = F_.resize_bilinear_nhwc(c3a, h, w, addend=cfl)
+    c4l = F_.conv2d_auto(sl, dev(w4), dev(b4), stride=1, padding=0)
+    if c4l.shape[-1] != xa.shape[-1]:
+        c4l = torch.nn.functional.pad(c4l, (0, xa.shape[-1] - c4l.shape[-1])) if c4l.shape[-1] < xa.shape[-1] else c4l[..., :xa.shape[-1]].contiguous()
+    lay = F_.nhwc_bf16_to_nchw_f32(F_.sigmoid_gate(xa, c4l), cf_).cpu().numpy()
+    assert np.abs(got_n - lay).max() <= 2e-2 * max(1.0, float(np.abs(x).max()))
+    assert np.mean(got_n != lay) <= 0.05
