@@ -200,6 +200,31 @@ SRHIP_API int srhip_conv_gemm_pack_weights(const float* weight, void* packed, in
                                            void* stream);
 SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* args, void* stream);
 
+/* A chain of three 1x1 convolutions, each + bias + activation, as ONE pass: the maps between the layers never leave the
+ * CU.  Replaces three launches of srhip_conv_gemm_fwd with ksize 1 on the tails of the temporal network's G-buffer encoder
+ * (core/models/model_final.py:237-246: conv_main[1:4] 160 -> 160 -> 160 -> 64 and conv_enhance[1:4] 112 -> 64 -> 64 -> 64,
+ * the second scaled by enhance_param and added to the first, :256-258):
+ *   dst = alpha * act2(W2 act1(W1 act0(W0 src + b0) + b1) + b2) + res
+ * src (npix, c[0]), dst / res (npix, c[3]) NHWC bf16, channels contiguous per pixel; wpack[l]: layer l packed by
+ * srhip_conv_gemm_pack_weights(ksize 1, cin_padded = c[l]); bias[l] fp32 (c[l+1]) or NULL; the intermediate maps are
+ * rounded to bf16 as the layer-by-layer form stores them, sums in fp32 in the same order (results are bit-equal).
+ * Kernels exist for (160,160,160,64) without residual and (112,64,64,64) with one: srhip_conv1x1_chain_supported says. */
+typedef struct {
+    const void* src;
+    const void* res;      /* NULL, or the map added behind alpha * act(.) */
+    void* dst;
+    const void* wpack[3];
+    const float* bias[3];
+    long long npix;       /* N * H * W */
+    int c[4];             /* channels: input, after layer 0, 1, 2 (multiples of 16) */
+    int nlayers;          /* 3 */
+    int act[3];           /* SRHIP_ACT_* per layer */
+    float slope;          /* LeakyReLU slope */
+    float alpha;          /* > 0 */
+} srhip_conv1x1_chain_args;
+SRHIP_API int srhip_conv1x1_chain_fwd(const srhip_conv1x1_chain_args* a, void* stream);
+SRHIP_API int srhip_conv1x1_chain_supported(const int* c, int nlayers, int has_res);
+
 /* Weight and bias gradient of the same layer (autograd backward of nn.Conv2d,
  * core/models/model.py:12,26-28,112-114 via loss.backward() at core/trainer.py:160):
  *   dw[co][ci_off+ci][ky][kx] (=|+=) scale * sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]

@@ -68,6 +68,14 @@ class ConvGemmArgs(ctypes.Structure):
     ]
 
 
+class Conv1x1ChainArgs(ctypes.Structure):
+    """srhip_conv1x1_chain_args"""
+    _fields_ = [
+        ("src", c_void_p), ("res", c_void_p), ("dst", c_void_p), ("wpack", c_void_p * 3), ("bias", c_void_p * 3),
+        ("npix", ctypes.c_longlong), ("c", c_int * 4), ("nlayers", c_int), ("act", c_int * 3), ("slope", c_float), ("alpha", c_float),
+    ]
+
+
 _SIGNATURES = {
     "srhip_version": (c_int, []),
     "srhip_last_error": (ctypes.c_char_p, []),
@@ -83,6 +91,8 @@ _SIGNATURES = {
     "srhip_conv_gemm_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_conv_gemm_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "srhip_conv_gemm_fwd": (c_int, [ctypes.POINTER(ConvGemmArgs), c_void_p]),
+    "srhip_conv1x1_chain_fwd": (c_int, [ctypes.POINTER(Conv1x1ChainArgs), c_void_p]),
+    "srhip_conv1x1_chain_supported": (c_int, [ctypes.POINTER(c_int), c_int, c_int]),
     "srhip_conv3x3_wgrad_workspace_bytes": (c_size_t, []),
     "srhip_conv3x3_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float, c_void_p]),
     "srhip_conv3x3_wgrad_windows": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float] + [c_int] * 4 + [c_void_p]),

@@ -335,11 +335,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                     for (int e = 0; e < 4; ++e) {
                         const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
                         const float t = acc[pt][ct][4 * g + e] + bia;
-                        v[e] = fmaxf(t, t * p.slope) * p.alpha;   // act(t) = max(t, slope * t), slope in {1, 0, s}
+                        v[e] = fmaxf(t, t * p.slope);   // act(t) = max(t, slope * t), slope in {1, 0, s}
                     }
                     if (rp != nullptr && c0 < p.cout_w) {
                         const uint2 r = *(const uint2*)(rp + c0 * 2);
-                        v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                        const float rf[4] = {bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, rf[e]);   // one rounding, whatever the contraction mode
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
                     }
                     *(uint2*)(ow + px * C::OUT_ROWB + cl * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
@@ -383,11 +388,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                 for (int e = 0; e < 4; ++e) {
                     const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
                     const float t = acc[pt][ct][4 * g + e] + bia;
-                    v[e] = fmaxf(t, t * p.slope) * p.alpha;   // act(t) = max(t, slope * t), slope in {1, 0, s}
+                    v[e] = fmaxf(t, t * p.slope);   // act(t) = max(t, slope * t), slope in {1, 0, s}
                 }
                 if (rp != nullptr) {
                     const uint2 r = *(const uint2*)(rp + c0 * 2);
-                    v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                    const float rf[4] = {bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, rf[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
                 }
                 *(uint2*)(dp + c0 * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from ._lib import ConvGemmArgs, Conv3x3Args, Conv3x3PairArgs, check, lib
+from ._lib import Conv1x1ChainArgs, ConvGemmArgs, Conv3x3Args, Conv3x3PairArgs, check, lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 RES_ADD, RES_MASK, RES_PRE = 0, 1, 2
@@ -581,6 +581,49 @@ def conv_gemm(srcs, wpack: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     a.n, a.h, a.w, a.cout, a.cout_stride = n, h, w, cout, out.shape[3]
     a.ksize, a.stride, a.pad, a.act, a.slope, a.alpha = ksize, stride, padding, act, slope, alpha
     check(lib.srhip_conv_gemm_fwd(a, _stream()))
+    return out
+
+
+def conv1x1_chain_supported(channels, has_res: bool) -> bool:
+    """Whether ``conv1x1_chain`` has a kernel for this chain of channel counts (input, after each layer)."""
+    if len(channels) != 4 or os.environ.get("SRHIP_NO_CHAIN", "0") == "1":
+        return False
+    import ctypes
+    return bool(lib.srhip_conv1x1_chain_supported((ctypes.c_int * 4)(*channels), 3, int(has_res)))
+
+
+def conv1x1_chain(x: torch.Tensor, layers, alpha: float = 1.0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """alpha * act2(W2 act1(W1 act0(W0 x + b0) + b1) + b2) + res: three 1x1 convolutions in one pass, the maps between them
+    kept on chip (rounded to bf16 as the layer-by-layer form stores them).  ``layers``: three (weight (O,I,1,1) fp32, bias or
+    None, act) with channel counts that are multiples of 16; x (N,H,W,I0) bf16, the result (N,H,W,O2)."""
+    x = _req(x, torch.bfloat16, "x")
+    if len(layers) != 3:
+        raise ValueError("conv1x1_chain: three layers")
+    a = Conv1x1ChainArgs()
+    chans = [x.shape[-1]]
+    keep = []
+    for l, (wt, b, act) in enumerate(layers):
+        cout, cin = wt.shape[0], wt.shape[1]
+        if tuple(wt.shape[2:]) != (1, 1) or cin != chans[-1] or cout % 16 or cin % 16:
+            raise ValueError("conv1x1_chain: 1x1 kernels whose channel counts chain up, all multiples of 16")
+        wp = _cached_pack(wt, ("gemm", cin), lambda wt=wt, cin=cin: conv_gemm_pack_weights(wt.detach().float().contiguous(), cin))
+        bb = None if b is None else _req(b.detach(), torch.float32, "bias")
+        keep.append((wp, bb))
+        a.wpack[l], a.bias[l], a.act[l] = wp.data_ptr(), _ptr(bb), act
+        chans.append(cout)
+    if not conv1x1_chain_supported(chans, res is not None):
+        raise ValueError(f"conv1x1_chain: no kernel for the chain {chans} {'with' if res is not None else 'without'} residual")
+    out = torch.empty(x.shape[:-1] + (chans[-1],), dtype=torch.bfloat16, device=x.device)
+    if res is not None:
+        res = _req(res, torch.bfloat16, "res")
+        if res.shape != out.shape:
+            raise ValueError("conv1x1_chain: residual shape must equal the output shape")
+    a.src, a.res, a.dst = x.data_ptr(), _ptr(res), out.data_ptr()
+    a.npix = x.shape[0] * x.shape[1] * x.shape[2]
+    for i in range(4):
+        a.c[i] = chans[i]
+    a.nlayers, a.slope, a.alpha = 3, 0.0, alpha
+    check(lib.srhip_conv1x1_chain_fwd(a, _stream()))
     return out
 
 

@@ -177,7 +177,14 @@ class GBuffersEncoder(nn.Module):
             fn, vmax = F_.pixel_unshuffle_to_nhwc_bf16(buffer, self.factor, want_max=True)
         else:
             fn, vmax = F_.pixel_unshuffle_to_nhwc_bf16(buffer, self.factor), None
-        fmap = _run_seq(self.conv_main, fn)
+        # the three 1x1 layers behind each 3x3 layer as one pass (inference; recorded passes keep every layer's map)
+        chain = not torch.is_grad_enabled() and _TRACE is None
+        tail = lambda seq: [(m[0].weight, m[0].bias, F_.ACT_RELU) for m in list(seq)[1:]]
+        chans = lambda seq: [seq[1][0].in_channels] + [m[0].out_channels for m in list(seq)[1:]]
+        if chain and len(self.conv_main) == 4 and F_.conv1x1_chain_supported(chans(self.conv_main), False):
+            fmap = F_.conv1x1_chain(self.conv_main[0].run(fn), tail(self.conv_main))
+        else:
+            fmap = _run_seq(self.conv_main, fn)
         # picked from the converted map (the conversion rounds element by element, so the order does not matter)
         if not torch.is_grad_enabled() and r2 % 16 == 0:
             e = ((fn, 0, 3 * r2), (fn, 6 * r2, 4 * r2))   # the first enhance layer reads the two channel windows in place
@@ -186,6 +193,9 @@ class GBuffersEncoder(nn.Module):
             e = torch.cat((f32[..., 0:3 * r2 // 2], f32[..., 3 * r2:5 * r2]), dim=-1).view(torch.bfloat16)
         else:
             e = torch.cat((fn[..., 0:3 * r2], fn[..., 6 * r2:10 * r2]), dim=-1)
+        if chain and len(self.conv_enhance) == 4 and F_.conv1x1_chain_supported(chans(self.conv_enhance), True):
+            # ... and fmap + enhance_param * (the chain's result) on its last epilogue
+            return F_.conv1x1_chain(self.conv_enhance[0].run(e), tail(self.conv_enhance), alpha=self._enhance_scale(), res=fmap), vmax
         for m in list(self.conv_enhance)[:-1]:
             e = m.run(e)
         last = self.conv_enhance[-1][0]

@@ -87,7 +87,7 @@ def _header_struct_fields(name: str):
         decl = " ".join(decl.split())
         if not decl:
             continue
-        m = re.match(r"(const void\*|void\*|const float\*|float\*|int|float)\s+(.*)", decl)
+        m = re.match(r"(const void\*|void\*|const float\*|float\*|long long|int|float)\s+(.*)", decl)
         assert m, decl
         for fld in m.group(2).split(","):
             out.append((m.group(1), fld.strip()))
@@ -98,7 +98,7 @@ def _expected_layout(fields):
     """Offsets and size the C compiler gives these fields on x86-64 / LP64 (natural alignment)."""
     off, offs, align_max = 0, {}, 1
     for typ, fld in fields:
-        size = 8 if "*" in typ else 4
+        size = 8 if ("*" in typ or typ == "long long") else 4
         cnt = 1
         m = re.match(r"(\w+)\[(\d+)\]", fld)
         if m:
@@ -113,7 +113,7 @@ def _expected_layout(fields):
 def test_every_args_struct_matches_the_header_field_for_field():
     from superresolution_amd import _lib
     for cname, cls in (("srhip_conv3x3_args", _lib.Conv3x3Args), ("srhip_conv3x3_pair_args", _lib.Conv3x3PairArgs),
-                       ("srhip_conv_gemm_args", _lib.ConvGemmArgs)):
+                       ("srhip_conv_gemm_args", _lib.ConvGemmArgs), ("srhip_conv1x1_chain_args", _lib.Conv1x1ChainArgs)):
         fields = _header_struct_fields(cname)
         offs, size = _expected_layout(fields)
         names = [re.sub(r"\[\d+\]", "", f) for _, f in fields]
@@ -122,7 +122,7 @@ def test_every_args_struct_matches_the_header_field_for_field():
         for fld, off in offs.items():
             assert getattr(cls, fld).offset == off, (cname, fld)
     assert ctypes.sizeof(_lib.Conv3x3Args) == 128 and ctypes.sizeof(_lib.Conv3x3PairArgs) == 104
-    assert ctypes.sizeof(_lib.ConvGemmArgs) == 136
+    assert ctypes.sizeof(_lib.ConvGemmArgs) == 136 and ctypes.sizeof(_lib.Conv1x1ChainArgs) == 120
 
 
 def integration_snippet() -> str:

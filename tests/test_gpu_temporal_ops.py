@@ -301,3 +301,44 @@ def test_fused_tail_pixel_shuffle_conv_relu(F_, shape):
     assert float((got.cpu() - TF.conv2d(TF.pixel_shuffle(x[..., :48].float().permute(0, 3, 1, 2), 4), wgt, None, padding=1)).abs().max()) <= 1e-4
     with pytest.raises(ValueError):
         F_.pixel_shuffle4_conv3x3_c3(x.cuda(), wgt[:2].cuda(), bias.cuda())
+
+
+@pytest.mark.parametrize("case", [((160, 160, 160, 64), False, (1, 37, 53)), ((112, 64, 64, 64), True, (2, 19, 70)),
+                                  ((160, 160, 160, 64), False, (1, 1, 5)), ((112, 64, 64, 64), True, (1, 96, 130)),
+                                  ((160, 160, 160, 64), False, (1, 136, 240))])
+def test_conv1x1_chain_equals_the_three_layers(case):
+    """The 1x1 tails of the G-buffer encoder (core/models/model_final.py:237-246, :256-258) as one launch: bit-equal to the
+    three implicit-GEMM launches it replaces (same bf16 rounding of the maps between the layers, same fp32 sums in the same
+    order), and within 2e-2 of the oracle's convolutions with those maps rounded to bf16."""
+    from superresolution_amd import functional as F_
+    chans, has_res, (n, h, w) = case
+    g = torch.Generator().manual_seed(h * 31 + w)
+    x = (torch.rand(n, h, w, chans[0], generator=g) - 0.3).to(torch.bfloat16).cuda()
+    layers = []
+    for l in range(3):
+        wt = (torch.randn(chans[l + 1], chans[l], 1, 1, generator=g) * (1.5 / chans[l] ** 0.5)).cuda()
+        b = (torch.randn(chans[l + 1], generator=g) * 0.1).cuda()
+        layers.append((wt, b, F_.ACT_RELU))
+    res = (torch.rand(n, h, w, chans[3], generator=g) - 0.5).to(torch.bfloat16).cuda() if has_res else None
+    alpha = 0.45 if has_res else 1.0
+    assert F_.conv1x1_chain_supported(list(chans), has_res)
+    got = F_.conv1x1_chain(x, layers, alpha=alpha, res=res)
+    t = x
+    for l, (wt, b, act) in enumerate(layers):
+        last = l == 2
+        t = F_.conv2d_auto(t, wt, b, stride=1, padding=0, act=act, alpha=alpha if last else 1.0, res=res if last else None)
+    torch.cuda.synchronize()
+    assert got.shape == t.shape
+    assert torch.equal(got, t), float((got.float() - t.float()).abs().max())
+    if h * w <= 4000:
+        r = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+        o = x.float().permute(0, 3, 1, 2).cpu().numpy()
+        for l, (wt, b, act) in enumerate(layers):
+            wq = wt.to(torch.bfloat16).float().cpu().numpy()
+            o = orc.conv2d(o, wq, b.cpu().numpy(), 1, 0, act=1)
+            if l < 2:
+                o = r(o)
+        o = alpha * o + (res.float().permute(0, 3, 1, 2).cpu().numpy() if has_res else 0.0)
+        assert np.abs(got.float().permute(0, 3, 1, 2).cpu().numpy() - o).max() <= 2e-2 * max(1.0, float(np.abs(o).max()))
+    # an unsupported chain is refused, not mis-run
+    assert not F_.conv1x1_chain_supported([64, 64, 64, 64], False)

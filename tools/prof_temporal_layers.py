@@ -54,7 +54,7 @@ wrap("conv_gemm", gemm_info)
 wrap("conv3x3", c3_info)
 for nm in ("conv_transpose2x2s2", "attention_fuse", "resize_bilinear_nhwc", "pixel_shuffle4_conv3x3_c3", "pixel_unshuffle_to_nhwc_bf16",
            "gradient_map_unshuffle_nhwc", "max_pool2d_nhwc", "sigmoid_gate", "layernorm_cf", "conv2d_direct", "pixel_shuffle_nhwc_to_nchw_f32",
-           "nchw_f32_to_nhwc_bf16", "esa_tail", "warp_concat_nhwc", "disocclusion", "concat_nhwc", "add_bf16"):
+           "nchw_f32_to_nhwc_bf16", "esa_tail", "conv1x1_chain", "backward_warp", "backward_warp_nhwc", "dilate_velocity", "clamp_depth", "warp_concat_nhwc", "disocclusion", "concat_nhwc", "add_bf16"):
     if hasattr(F_, nm):
         wrap(nm, lambda a, k, out: ("", 0.0))
 
