@@ -29,6 +29,7 @@
 //     residual, bf16 pack, one 8-byte store.
 // -DGEMM_EXP=<bits> builds timing-only variants: 1 no weight loads, 2 no input loads after the first stage, 4 no stores.
 #include <atomic>
+#include <cstdlib>
 
 #include "srhip_common.h"
 
@@ -452,7 +453,13 @@ int launch_gemm_nt(GemmParams p, int groups, hipStream_t stream)
 template <int KS, int S>
 int launch_gemm(const GemmParams& p, hipStream_t stream)
 {
-    const int maxnt = MAXNT;
+    // Small images: fewer output tiles per work-group give more work-groups (each re-stages the input window, which the
+    // XCD's L2 holds).  Measured at 68 x 120 and 136 x 240 (256 -> 256: 36 -> 28 us with one tile per group, 192 -> 192:
+    // 45 -> 38 us with two); from about 400 work-groups on, the widest grouping wins again.
+    int maxnt = MAXNT;
+    const long long tiles = (long long)srhip_div_up(p.wo, TPX) * srhip_div_up(p.ho, ROWS) * p.n;
+    while (maxnt > (S == 2 ? 2 : 1) && tiles * srhip_div_up(p.ct_total, maxnt) < 400) --maxnt;
+    if (const char* e = getenv("SRHIP_GEMM_NT")) maxnt = atoi(e) >= 1 && atoi(e) <= MAXNT ? atoi(e) : MAXNT;   // timing experiments
     const int groups = srhip_div_up(p.ct_total, maxnt);
     const int nt = srhip_div_up(p.ct_total, groups);
     switch (nt) {

@@ -299,7 +299,22 @@ class Attention(nn.Module):
         self.w_cross = ConvActivation(cin, 1)
 
     def run(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
-        return self.conv.run(x), self.w_self.run(x)[..., 0:1], self.w_cross.run(x)[..., 0:1]
+        if torch.is_grad_enabled() or _TRACE is not None:
+            return self.conv.run(x), self.w_self.run(x)[..., 0:1], self.w_cross.run(x)[..., 0:1]
+        # inference: the two one-channel layers read the same map -> one launch with both kernels (channels 0 and 1)
+        w2, b2 = self._gate_kernels()
+        gates = F_.conv2d_auto(x, w2, b2, stride=1, padding=1, act=F_.ACT_RELU)
+        return self.conv.run(x), gates[..., 0:1], gates[..., 1:2]
+
+    def _gate_kernels(self):
+        """w_self's and w_cross's kernels and biases stacked (2, cin, 3, 3) / (2,), cached until a parameter changes."""
+        ps = (self.w_self[0].weight, self.w_cross[0].weight, self.w_self[0].bias, self.w_cross[0].bias)
+        tag = tuple((p._version, p.data_ptr()) for p in ps)
+        hit = getattr(self, "_gate_cache", None)
+        if hit is None or hit[0] != tag:
+            hit = (tag, (torch.cat((ps[0].detach(), ps[1].detach()), dim=0).contiguous(), torch.cat((ps[2].detach(), ps[3].detach())).contiguous()))
+            object.__setattr__(self, "_gate_cache", hit)
+        return hit[1]
 
 
 class MainNetwork(nn.Module):
