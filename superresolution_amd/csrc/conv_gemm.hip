@@ -92,7 +92,8 @@ struct GCfg {
     // epilogue staging: per wave 64 pixels x (NT * 32 channels bf16 + 16 B padding), pixel-major
     static constexpr int OUT_ROWB = NT * 64 + 16;
     static constexpr int OUT_WAVE = 64 * OUT_ROWB;
-    static constexpr int LDS_BYTES = STAGE_LDS > 4 * OUT_WAVE ? STAGE_LDS : 4 * OUT_WAVE;
+    static constexpr int BIAS_OFF = STAGE_LDS > 4 * OUT_WAVE ? STAGE_LDS : 4 * OUT_WAVE;   // the group's NT * 32 biases (fp32)
+    static constexpr int LDS_BYTES = BIAS_OFF + NT * 32 * 4;
     static_assert(NSTEP * NT * 1024 < 65536, "weight fragments are addressed by the LDS instruction's 16-bit offset");
 };
 
@@ -161,6 +162,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     const int ct0 = grp * NT;
     const int nt = min(NT, p.ct_total - ct0);   // < NT only in the last group: its missing tiles read zero weights
 
+    // the group's biases -> LDS: the epilogue reads them there (a global load per accumulator quad would be a memory round
+    // trip of its own at a point where nothing is left to hide it)
+    if (tid < NT * 32) {
+        const int c = ct0 * 32 + tid;
+        ((float*)(smem + C::BIAS_OFF))[tid] = (p.bias != nullptr && c < p.cout) ? p.bias[c] : 0.0f;
+    }
     // All global loads are buffer loads whose out-of-image / out-of-range pieces carry an offset that fails the bounds
     // check and come back as zeros: no branches in the load phase.
     // per-thread pieces of the input window: pixel index inside the image, constant over the chunks
@@ -332,10 +339,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                 for (int g = 0; g < 4; ++g) {
                     const int cl = ct * 32 + 8 * g + 4 * hl, c0 = ct0 * 32 + cl;
                     float v[4];
+                    const float4 bia = *(const float4*)(smem + C::BIAS_OFF + cl * 4);
+                    const float biav[4] = {bia.x, bia.y, bia.z, bia.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
-                        const float t = acc[pt][ct][4 * g + e] + bia;
+                        const float t = acc[pt][ct][4 * g + e] + biav[e];
                         v[e] = fmaxf(t, t * p.slope);   // act(t) = max(t, slope * t), slope in {1, 0, s}
                     }
                     if (rp != nullptr && c0 < p.cout_w) {
@@ -385,10 +393,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                 const int c0 = (ct0 + ct) * 32 + 8 * g + 4 * hl;
                 if (c0 >= p.cout_w) continue;
                 float v[4];
+                const float4 bia = *(const float4*)(smem + C::BIAS_OFF + (c0 - ct0 * 32) * 4);
+                const float biav[4] = {bia.x, bia.y, bia.z, bia.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float bia = (p.bias != nullptr && c0 + e < p.cout) ? p.bias[c0 + e] : 0.0f;
-                    const float t = acc[pt][ct][4 * g + e] + bia;
+                    const float t = acc[pt][ct][4 * g + e] + biav[e];
                     v[e] = fmaxf(t, t * p.slope);   // act(t) = max(t, slope * t), slope in {1, 0, s}
                 }
                 if (rp != nullptr) {

@@ -112,3 +112,4 @@ def test_conv_gemm_rejects_bad_arguments(F_):
         F_.conv_gemm(x, wp, None, 8, 3, stride=3, padding=1)
     with pytest.raises(SrhipError):
         F_.conv_gemm(x, wp, None, 8, 3, padding=1, alpha=0.0)
+
