@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINT = os.path.join(ROOT, "tools", "isa_lint.py")
-KERNELS = ["conv3x3_mfma.hip", "conv3x3_wgrad.hip", "conv3x3_pair.hip", "conv_gemm.hip"]
+KERNELS = ["conv3x3_mfma.hip", "conv3x3_wgrad.hip", "conv3x3_pair.hip", "conv_gemm.hip", "conv1x1_chain.hip"]
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
@@ -38,7 +38,7 @@ def test_no_compiler_formed_packed_fp32_in_the_vector_alu_kernels(tmp_path):
     makefile = open(os.path.join(ROOT, "superresolution_amd", "csrc", "Makefile")).read()
     flagged = [ln for ln in makefile.splitlines() if ln.rstrip().endswith("CXXFLAGS += -fno-slp-vectorize")]
     assert len(flagged) == 1
-    for obj in ("memops.o", "loss.o", "conv_direct.o", "conv3x3_mfma.o", "conv3x3_pair.o", "conv_gemm.o", "conv3x3_wgrad.o"):
+    for obj in ("memops.o", "loss.o", "conv_direct.o", "conv3x3_mfma.o", "conv3x3_pair.o", "conv_gemm.o", "conv1x1_chain.o", "conv3x3_wgrad.o"):
         assert obj in flagged[0], obj
     allowed = ("upsample_int_nhwc_kernel", "layernorm_cf", "ssim_fwd_kernel", "ssim_bwd_kernel")
 
