@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""A few launches of one of the kernels added last (for rocprofv3 counter passes):
+    rocprofv3 --pmc <counters> -- python3 tools/prof_new_kernels.py <case>
+cases: chain (160-160-160-64 1x1 chain at 544x960), chain_res (112-64-64-64 + residual), esa (ESA tail at 540x960 x 48),
+pairbwd (both data gradients of an SRResidualBlock at 16 x 1024 x 1024), pairbits (the forward launch that emits the bits)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from superresolution_amd import functional as F_
+
+dev = torch.device("cuda")
+case = sys.argv[1] if len(sys.argv) > 1 else "chain"
+g = torch.Generator(device="cuda").manual_seed(1)
+rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) - 0.5)
+REP = 6
+if case in ("chain", "chain_res"):
+    ch = (160, 160, 160, 64) if case == "chain" else (112, 64, 64, 64)
+    x = rnd(1, 544, 960, ch[0]).to(torch.bfloat16)
+    layers = [((rnd(ch[l + 1], ch[l], 1, 1) * 0.2).float(), rnd(ch[l + 1]) * 0.1, F_.ACT_RELU) for l in range(3)]
+    res = rnd(1, 544, 960, 64).to(torch.bfloat16) if case == "chain_res" else None
+    for _ in range(REP):
+        F_.conv1x1_chain(x, layers, alpha=0.45 if res is not None else 1.0, res=res)
+elif case == "esa":
+    x, c1, c3 = rnd(1, 540, 960, 48).to(torch.bfloat16), rnd(1, 540, 960, 16).to(torch.bfloat16), rnd(1, 88, 158, 16).to(torch.bfloat16)
+    wf, w4 = rnd(16, 16) * 0.3, rnd(48, 16) * 0.3
+    for _ in range(REP):
+        F_.esa_tail(x, c1, c3, wf, rnd(16) * 0.1, w4, rnd(48) * 0.1, 48)
+else:
+    n, h, w = 16, 1024, 1024
+    x = rnd(n, h, w, 64).to(torch.bfloat16)
+    w1, w2 = rnd(64, 64, 3, 3) * 0.1, rnd(64, 64, 3, 3) * 0.1
+    wp1, wp2 = F_.conv3x3_pack_weights(w1, 64, 64), F_.conv3x3_pack_weights(w2, 64, 64)
+    b1, b2 = rnd(64) * 0.1, rnd(64) * 0.1
+    out, mid, bits = F_.conv3x3_pair(x, wp1, b1, wp2, b2, act2=F_.ACT_NONE, alpha=0.2, emit_bits=True)
+    if case == "pairbits":
+        for _ in range(REP - 1):
+            F_.conv3x3_pair(x, wp1, b1, wp2, b2, act2=F_.ACT_NONE, alpha=0.2, emit_bits=True)
+    else:
+        wtb = F_.conv3x3_pack_weights(w2, 64, 64, transpose_flip=True)
+        wta = F_.conv3x3_pack_weights(w1, 64, 64, transpose_flip=True)
+        for _ in range(REP):
+            F_.conv3x3_pair(x, wtb, None, wta, None, act2=F_.ACT_NONE, alpha=0.2, apply_bits=bits)
+torch.cuda.synchronize()
