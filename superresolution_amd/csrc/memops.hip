@@ -6,6 +6,8 @@
 
 #include <mutex>
 
+#include <cstdlib>
+
 #include "srhip_common.h"
 
 // The coordinate / index arithmetic below replays the reference's fp32 operator sequence one
@@ -406,6 +408,71 @@ __global__ void upsample_bwd_nhwc_kernel(const unsigned short* __restrict__ ddst
                                          pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
     }
 }
+// The same gather for the integer ratio R (th = R sh, tw = R sw): the taps with a non-zero weight are 2 R consecutive
+// target columns / rows starting at R s - R / 2, so a thread evaluates 2 R + 2 R tap weights (the very same fp32 coordinate
+// replay as above) instead of one per visited (row, column) pair, and its 2 R loads of a row are independent.  Same
+// products, same order of the sum: bit-equal to the kernel above.
+template <int R>
+__global__ __launch_bounds__(kThreads) void upsample_bwd_int_nhwc_kernel(const unsigned short* __restrict__ ddst,
+                                                                        const unsigned short* __restrict__ relu_out,
+                                                                        unsigned short* __restrict__ dsrc, int n, int c, int sh, int sw,
+                                                                        CoordAxis ax, CoordAxis ay)
+{
+    constexpr int NT = 2 * R;
+    const int cg = c / 8, th = R * sh, tw = R * sw;
+    const long long total = (long long)n * sh * sw * cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long long p = i / cg;
+        const int sx = (int)(p % sw); p /= sw;
+        const int sy = (int)(p % sh);
+        const int img = (int)(p / sh);
+        const int x0 = R * sx - R / 2, y0 = R * sy - R / 2;
+        float wx[NT], wy[NT];
+        int xi[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int x = x0 + t, y = y0 + t;
+            wx[t] = (x >= 0 && x < tw) ? tap_weight(ax, x, sw, sx) : 0.0f;
+            wy[t] = (y >= 0 && y < th) ? tap_weight(ay, y, sh, sy) : 0.0f;
+            xi[t] = min(max(x, 0), tw - 1);
+        }
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ty = 0; ty < NT; ++ty) {
+            const int y = min(max(y0 + ty, 0), th - 1);
+            const unsigned short* row = ddst + (((long long)img * th + y) * tw) * c + g * 8;
+            uint4 v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = *(const uint4*)(row + (long long)xi[t] * c);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float wgt = __fmul_rn(wx[t], wy[ty]);
+                if (wx[t] != 0.0f && wy[ty] != 0.0f) {   // taps with a zero weight are skipped, not added as 0 * v
+                    acc[0] += bf16_lo(v[t].x) * wgt; acc[1] += bf16_hi(v[t].x) * wgt;
+                    acc[2] += bf16_lo(v[t].y) * wgt; acc[3] += bf16_hi(v[t].y) * wgt;
+                    acc[4] += bf16_lo(v[t].z) * wgt; acc[5] += bf16_hi(v[t].z) * wgt;
+                    acc[6] += bf16_lo(v[t].w) * wgt; acc[7] += bf16_hi(v[t].w) * wgt;
+                }
+            }
+        }
+        const long long o = (((long long)img * sh + sy) * sw + sx) * c + g * 8;
+        if (relu_out != nullptr) {
+            const uint4 m = *(const uint4*)(relu_out + o);
+            if (!(bf16_lo(m.x) > 0.0f)) acc[0] = 0.0f;
+            if (!(bf16_hi(m.x) > 0.0f)) acc[1] = 0.0f;
+            if (!(bf16_lo(m.y) > 0.0f)) acc[2] = 0.0f;
+            if (!(bf16_hi(m.y) > 0.0f)) acc[3] = 0.0f;
+            if (!(bf16_lo(m.z) > 0.0f)) acc[4] = 0.0f;
+            if (!(bf16_hi(m.z) > 0.0f)) acc[5] = 0.0f;
+            if (!(bf16_lo(m.w) > 0.0f)) acc[6] = 0.0f;
+            if (!(bf16_hi(m.w) > 0.0f)) acc[7] = 0.0f;
+        }
+        *(uint4*)(dsrc + o) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                                         pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+    }
+}
+
 
 // element-wise training helpers: 8 bf16 per thread
 __device__ __forceinline__ unsigned mask2(unsigned dy, unsigned y)
@@ -2214,6 +2281,12 @@ SRHIP_API int srhip_upsample_grid_bilinear_bwd_nhwc(const void* ddst, const void
     SRHIP_REQUIRE(ddst && dsrc, "upsample_grid_bilinear_bwd_nhwc: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 8 && c % 8 == 0 && sh >= 1 && sw >= 1 && th >= 1 && tw >= 1, "upsample_grid_bilinear_bwd_nhwc: bad shape (c must be a multiple of 8)");
     const long long work = (long long)n * sh * sw * (c / 8);
+    if (th == 4 * sh && tw == 4 * sw && getenv("SRHIP_NO_UPBWD_INT") == nullptr) {   // the network's ratio: 8 + 8 tap weights per thread
+        hipLaunchKernelGGL(upsample_bwd_int_nhwc_kernel<4>, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                           (const unsigned short*)ddst, (const unsigned short*)relu_out, (unsigned short*)dsrc, n, c, sh, sw,
+                           coord_axis(tw), coord_axis(th));
+        return srhip_check_launch("upsample_bwd_int_nhwc");
+    }
     hipLaunchKernelGGL(upsample_bwd_nhwc_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const unsigned short*)ddst, (const unsigned short*)relu_out, (unsigned short*)dsrc, n, c, sh, sw, th, tw,
                        coord_axis(tw), coord_axis(th));

@@ -174,3 +174,20 @@ def test_upsample_bwd_nhwc_golden(F_, ops_golden):
     got = F_.upsample_grid_bilinear_bwd_nhwc(F_.nchw_f32_to_nhwc_bf16(dev(dy)), 5, 7)
     got = F_.nhwc_bf16_to_nchw_f32(got, 32).cpu().numpy()
     assert relerr(got, z["upbwd.dx"]) <= 2e-2
+
+
+@pytest.mark.parametrize("cfg", [(1, 1), (2, 3), (5, 7), (33, 20), (64, 64)])
+def test_upsample_bwd_integer_ratio_form_equals_the_general_gather(F_, cfg, monkeypatch):
+    """x4 (the network's ratio, core/models/model.py:153,162) runs a form with 8 + 8 tap weights per thread instead of
+    one per visited tap: same products, same order -- bit-equal, borders included."""
+    sh, sw = cfg
+    g = torch.Generator().manual_seed(sh * 50 + sw)
+    dy = (torch.rand(2, 4 * sh, 4 * sw, 32, generator=g) - 0.5).to(torch.bfloat16).cuda()
+    y = torch.relu(torch.rand(2, sh, sw, 32, generator=g) - 0.4).to(torch.bfloat16).cuda()
+    fast = F_.upsample_grid_bilinear_bwd_nhwc(dy, sh, sw, relu_out=y)
+    fast_nomask = F_.upsample_grid_bilinear_bwd_nhwc(dy, sh, sw)
+    monkeypatch.setenv("SRHIP_NO_UPBWD_INT", "1")
+    slow = F_.upsample_grid_bilinear_bwd_nhwc(dy, sh, sw, relu_out=y)
+    slow_nomask = F_.upsample_grid_bilinear_bwd_nhwc(dy, sh, sw)
+    torch.cuda.synchronize()
+    assert torch.equal(fast, slow) and torch.equal(fast_nomask, slow_nomask)
