@@ -1028,6 +1028,9 @@ def main():
             res["other_workloads"] = run_other_workloads(args, dev)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_crop)
+        if world > 1:
+            res["note"] = ("rank 0's line; value = frames of all ranks / max-over-ranks time; cpu_baseline and other_workloads are "
+                           "measured at N=1 only")
         emit(args, res)
     if dist is not None:
         dist.destroy_process_group()
