@@ -728,10 +728,11 @@ __global__ __launch_bounds__(kThreads) void esa_tail_kernel(const unsigned short
         const long long i = base + pl;
         const bool live = i < total;
         const long long ic = live ? i : total - 1;   // lanes past the end repeat the last pixel and store nothing
-        long long p = ic;
-        const int ox = (int)(p % w); p /= w;
-        const int oy = (int)(p % h);
-        const int img = (int)(p / h);
+        // (the host checks that the pixel count fits 31 bits: 32-bit divisions, a fraction of the 64-bit ones' instructions)
+        const unsigned pu = (unsigned)ic, rowi = pu / (unsigned)w;
+        const int ox = (int)(pu - rowi * (unsigned)w);
+        const int img = (int)(rowi / (unsigned)h);
+        const int oy = (int)(rowi - (unsigned)img * (unsigned)h);
         // every load of the step is issued before anything waits: x (the wave's 32 pixels are one contiguous piece of
         // memory, fetched 16 bytes per lane, whole cache lines per instruction), c1, the four taps of c3
         constexpr long long cbytes = CS * 2;
@@ -2362,6 +2363,7 @@ SRHIP_API int srhip_esa_tail_bf16(const void* x, const void* c1, const void* c3,
     SRHIP_REQUIRE(cfeat == 16 || cfeat == 32 || cfeat == 48 || cfeat == 64, "esa_tail_bf16: %d feature channels (16, 32, 48 or 64)", cfeat);
     SRHIP_REQUIRE(cstride == cfeat || cstride == 64, "esa_tail_bf16: channel stride %d (the %d feature channels, or 64)", cstride, cfeat);
     SRHIP_REQUIRE((size_t)x % 16 == 0 && (size_t)c1 % 16 == 0 && (size_t)c3 % 16 == 0 && (size_t)dst % 16 == 0, "esa_tail_bf16: maps must be 16-byte aligned");
+    SRHIP_REQUIRE((long long)n * h * w < (1ll << 31), "esa_tail_bf16: too many pixels for 32-bit indices");
     const long long work = (long long)n * h * w * 2;   // a wave covers 32 pixels per step
     const dim3 grid(grid_for(work, srhip_num_cus())), block(kThreads);
     hipStream_t s = (hipStream_t)stream;
