@@ -20,6 +20,8 @@
 //   finalize: sums the partials in a fixed order -> out[3] = {l1, ssim_loss, total}
 //
 // HBM-bound: 2 + 3 reads/writes in pass 1, 5 + 1 in pass 2 = 11 floats per pixel.
+#include <cstdlib>
+
 #include "srhip_common.h"
 
 namespace {
@@ -233,6 +235,235 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const LossParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming forms of the two passes.  The tile kernels above run load -> barrier -> filter -> barrier -> filter -> store
+// once per 32 x 32 tile with three 42-KB tiles per CU in flight, and that latency chain, not the traffic (exactly the
+// algorithmic bytes) or the arithmetic, sets their pace.  Here a work-group owns a strip of 256 columns (one thread per
+// column) and walks a segment of rows top to bottom:
+//   * each input row goes through a small LDS row buffer (266 values, double buffered, ONE barrier per row) for the
+//     horizontal 11-tap pass -- consecutive threads read consecutive addresses;
+//   * the vertical pass never touches LDS: a thread keeps the eleven output rows its column is still collecting in
+//     registers and adds g[k] * (this row's horizontal result) to output row r - k.  A row's first contribution is k = 0
+//     and its last k = 10, so each sum runs over k in ascending order, as in the tile kernels;
+//   * the row loop is unrolled eleven times so that "row r mod 11" names a register, not an index;
+//   * the next row's values are requested before the current row is filtered.
+// A segment re-filters the 10 halo rows above and below it (the host picks the segment height so that the launch has
+// about three work-groups per resident slot).
+constexpr int SW = 256;                 // columns per strip = threads per work-group
+constexpr int SROW = SW + 2 * HALO;     // values per staged row
+
+struct StreamParams {
+    LossParams p;
+    int strips, segs, seg_h, nunits;
+};
+
+template <int V>
+struct LInt { static constexpr int value = V; };
+template <int B, int E, class F>
+__device__ __forceinline__ void l_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(LInt<B>{});
+        l_for<B + 1, E>(f);
+    }
+}
+
+__global__ __launch_bounds__(SW) void ssim_fwd_stream_kernel(const StreamParams sp)
+{
+    const LossParams& p = sp.p;
+    __shared__ lf2 rowbuf[2][SROW + 2];
+    __shared__ float red[2][SW / 64];
+    const int tid = threadIdx.x;
+    const int per = (sp.nunits + 7) >> 3;   // XCD bands: vertical neighbours (which share halo rows) stay on one L2
+    int b = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (b >= sp.nunits) return;
+    const int unit = b;
+    const int seg = b % sp.segs; b /= sp.segs;
+    const int strip = b % sp.strips;
+    const int plane = b / sp.strips;
+    const int x0 = strip * SW, ys = seg * sp.seg_h;
+    const int nrows = min(sp.seg_h, p.h - ys);          // output rows of this segment
+    const int nsteps = nrows + 2 * HALO;                // input rows ys - 5 .. ys + nrows + 4
+    const long long base = (long long)plane * p.h * p.w;
+    const long long map = (long long)p.planes * p.h * p.w;
+    const int xc = x0 + tid;                            // this thread's output column
+    const int xa = x0 - HALO + tid, xb = x0 - HALO + SW + tid;   // the columns it stages (xb: threads 0..9 only)
+    const bool has_b = tid < 2 * HALO;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+
+    auto fetch = [&](const int r, lf2& va, lf2& vb) {   // input row r of the segment: image row ys - 5 + r
+        const int yy = ys - HALO + r;
+        va = lf2{0.0f, 0.0f}; vb = lf2{0.0f, 0.0f};
+        if (r < nsteps && yy >= 0 && yy < p.h) {
+            const long long ro = base + (long long)yy * p.w;
+            if (xa >= 0 && xa < p.w) va = lf2{clampf(p.sr[ro + xa], p.clip_min, p.clip_max), p.y[ro + xa]};
+            if (has_b && xb < p.w) vb = lf2{clampf(p.sr[ro + xb], p.clip_min, p.clip_max), p.y[ro + xb]};
+        }
+    };
+    lf2 A01[WIN], A23[WIN], ctr[WIN];
+    float A4[WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) { A01[k] = lf2{0.0f, 0.0f}; A23[k] = lf2{0.0f, 0.0f}; A4[k] = 0.0f; ctr[k] = lf2{0.0f, 0.0f}; }
+    float s_sum = 0.0f, l_sum = 0.0f;
+    // three rows are in flight ahead of the one being filtered (a row step is a few hundred cycles, a load a few thousand)
+    lf2 na, nb, na1, nb1, na2, nb2;
+    fetch(0, na, nb);
+    fetch(1, na1, nb1);
+    fetch(2, na2, nb2);
+    for (int rb = 0; rb < nsteps; rb += WIN) {
+        l_for<0, WIN>([&](auto ph_c) {
+            constexpr int ph = decltype(ph_c)::value;
+            const int r = rb + ph;
+            if (r < nsteps) {   // uniform over the work-group
+                rowbuf[r & 1][tid] = na;
+                if (has_b) rowbuf[r & 1][SW + tid] = nb;
+                na = na1; nb = nb1; na1 = na2; nb1 = nb2;
+                fetch(r + 3, na2, nb2);
+                __syncthreads();
+                lf2 q01 = lf2{0.0f, 0.0f}, q23 = lf2{0.0f, 0.0f};
+                float q4 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) {
+                    const lf2 v = rowbuf[r & 1][tid + k];
+                    const float g = p.g.w[k];
+                    q01 += g * v; q23 += g * (v * v); q4 += g * (v.x * v.y);
+                    if (k == HALO) ctr[ph] = v;
+                }
+                // this row is tap k of output row r - k, which lives in slot (ph - k) mod 11; tap 0 starts a new sum
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int slot = (ph - k + WIN) % WIN;
+                    const float g = p.g.w[k];
+                    if (k == 0) { A01[slot] = g * q01; A23[slot] = g * q23; A4[slot] = g * q4; }
+                    else { A01[slot] += g * q01; A23[slot] += g * q23; A4[slot] += g * q4; }
+                }
+                // output row o = r - 10 is complete (slot (ph + 1) mod 11); its centre pixel came with input row r - 5
+                const int o = r - 2 * HALO;
+                if (o >= 0 && xc < p.w) {
+                    constexpr int so = (ph + 1) % WIN, sc = (ph - HALO + WIN) % WIN;
+                    const float mx = A01[so].x, my = A01[so].y, exx = A23[so].x, eyy = A23[so].y, exy = A4[so];
+                    const float mx2 = mx * mx, my2 = my * my, mxy = mx * my;
+                    const float A1 = 2.0f * mxy + C1, A2 = 2.0f * (exy - mxy) + C2;
+                    const float B1 = mx2 + my2 + C1, B2 = (exx - mx2) + (eyy - my2) + C2;
+                    const float inv = 1.0f / (B1 * B2);
+                    const float S = A1 * A2 * inv;
+                    const float da = 2.0f * my * (A2 - A1) * inv - S * 2.0f * mx * (B2 - B1) * inv;
+                    const float db = -S / B2;
+                    const float dc = 2.0f * A1 * inv;
+                    const long long oidx = base + (long long)(ys + o) * p.w + xc;
+                    p.abc[oidx] = da; p.abc[map + oidx] = db; p.abc[2 * map + oidx] = dc;
+                    s_sum += S;
+                    l_sum += fabsf(ctr[sc].x - ctr[sc].y);
+                }
+            }
+        });
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s_sum += __shfl_down(s_sum, off);
+        l_sum += __shfl_down(l_sum, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s_sum; red[1][tid >> 6] = l_sum; }
+    __syncthreads();
+    if (tid == 0) {
+        p.partial[2 * unit] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p.partial[2 * unit + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(SW) void ssim_bwd_stream_kernel(const StreamParams sp)
+{
+    const LossParams& p = sp.p;
+    __shared__ lf2 rowab[2][SROW + 2];
+    __shared__ float rowc[2][SROW + 2];
+    const int tid = threadIdx.x;
+    const int per = (sp.nunits + 7) >> 3;
+    int b = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (b >= sp.nunits) return;
+    const int seg = b % sp.segs; b /= sp.segs;
+    const int strip = b % sp.strips;
+    const int plane = b / sp.strips;
+    const int x0 = strip * SW, ys = seg * sp.seg_h;
+    const int nrows = min(sp.seg_h, p.h - ys);
+    const int nsteps = nrows + 2 * HALO;
+    const long long base = (long long)plane * p.h * p.w;
+    const long long map = (long long)p.planes * p.h * p.w;
+    const int xc = x0 + tid;
+    const int xa = x0 - HALO + tid, xb = x0 - HALO + SW + tid;
+    const bool has_b = tid < 2 * HALO;
+
+    auto fetch = [&](const int r, lf2& va, float& ca, lf2& vb, float& cb) {
+        const int yy = ys - HALO + r;
+        va = lf2{0.0f, 0.0f}; vb = lf2{0.0f, 0.0f}; ca = 0.0f; cb = 0.0f;
+        if (r < nsteps && yy >= 0 && yy < p.h) {
+            const long long ro = base + (long long)yy * p.w;
+            if (xa >= 0 && xa < p.w) { va = lf2{p.abc[ro + xa], p.abc[map + ro + xa]}; ca = p.abc[2 * map + ro + xa]; }
+            if (has_b && xb < p.w) { vb = lf2{p.abc[ro + xb], p.abc[map + ro + xb]}; cb = p.abc[2 * map + ro + xb]; }
+        }
+    };
+    // sr and target of output row o (needed when that row's sums are complete): requested one step ahead
+    auto fetch_out = [&](const int o, float& raw, float& yv) {
+        raw = 0.0f; yv = 0.0f;
+        if (o >= 0 && o < nrows && xc < p.w) {
+            const long long oidx = base + (long long)(ys + o) * p.w + xc;
+            raw = p.sr[oidx]; yv = p.y[oidx];
+        }
+    };
+    lf2 Aab[WIN];
+    float Ac[WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) { Aab[k] = lf2{0.0f, 0.0f}; Ac[k] = 0.0f; }
+    lf2 na, nb, na1, nb1, na2, nb2;
+    float nca, ncb, nca1, ncb1, nca2, ncb2, oraw, oy, oraw1, oy1, oraw2, oy2;
+    fetch(0, na, nca, nb, ncb);
+    fetch(1, na1, nca1, nb1, ncb1);
+    fetch(2, na2, nca2, nb2, ncb2);
+    fetch_out(-2 * HALO, oraw, oy);
+    fetch_out(1 - 2 * HALO, oraw1, oy1);
+    fetch_out(2 - 2 * HALO, oraw2, oy2);
+    for (int rb = 0; rb < nsteps; rb += WIN) {
+        l_for<0, WIN>([&](auto ph_c) {
+            constexpr int ph = decltype(ph_c)::value;
+            const int r = rb + ph;
+            if (r < nsteps) {
+                rowab[r & 1][tid] = na; rowc[r & 1][tid] = nca;
+                if (has_b) { rowab[r & 1][SW + tid] = nb; rowc[r & 1][SW + tid] = ncb; }
+                const float raw = oraw, yv = oy;        // of output row r - 10
+                na = na1; nca = nca1; nb = nb1; ncb = ncb1; na1 = na2; nca1 = nca2; nb1 = nb2; ncb1 = ncb2;
+                oraw = oraw1; oy = oy1; oraw1 = oraw2; oy1 = oy2;
+                fetch(r + 3, na2, nca2, nb2, ncb2);
+                fetch_out(r + 3 - 2 * HALO, oraw2, oy2);
+                __syncthreads();
+                lf2 q = lf2{0.0f, 0.0f};
+                float q2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) {
+                    const float g = p.g.w[k];
+                    q += g * rowab[r & 1][tid + k]; q2 += g * rowc[r & 1][tid + k];
+                }
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) {
+                    const int slot = (ph - k + WIN) % WIN;
+                    const float g = p.g.w[k];
+                    if (k == 0) { Aab[slot] = g * q; Ac[slot] = g * q2; }
+                    else { Aab[slot] += g * q; Ac[slot] += g * q2; }
+                }
+                const int o = r - 2 * HALO;
+                if (o >= 0 && xc < p.w) {
+                    constexpr int so = (ph + 1) % WIN;
+                    const float xcv = clampf(raw, p.clip_min, p.clip_max);
+                    const float diff = xcv - yv;
+                    const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+                    float d = p.g_ssim * (Aab[so].x + 2.0f * xcv * Aab[so].y + yv * Ac[so]) + p.g_l1 * sgn;
+                    if (!(raw >= p.clip_min && raw <= p.clip_max)) d = 0.0f;  // clamp backward
+                    p.dsr[base + (long long)(ys + o) * p.w + xc] = d;
+                }
+            }
+        });
+    }
+}
+
 // One work-group of 1024 threads; every thread sums its partials four at a time (independent loads in flight: a
 // dependent chain of ~100 global loads per thread took 41 us for the 24,300 tiles of a 4K frame), then a fixed-order
 // tree in LDS: deterministic from run to run.
@@ -304,6 +535,36 @@ SRHIP_API int srhip_l1_ssim_loss(const float* sr, const float* target, float* ds
     for (int i = 0; i < WIN; ++i) p.g.w[i] = gs[i] / sum;
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = (int)nblocks;
+    // Streaming form for images that fill the chip with strips of 256 columns (the training crops, 4K frames): segments
+    // so that about three work-groups wait for each of the chip's resident slots (4 per CU), at least 32 rows each.
+    const int strips = srhip_div_up(w, SW);
+    const char* form = getenv("SRHIP_LOSS_FORM");   // "tiles" / "stream" force a form (tests, A/B timing)
+    const bool stream_auto = (long long)planes * strips * srhip_div_up(h, 32) >= 2ll * srhip_num_cus();
+    if (form != nullptr ? form[0] == 's' : stream_auto) {
+        StreamParams sp;
+        long long want = (12ll * srhip_num_cus() + (long long)planes * strips - 1) / ((long long)planes * strips);
+        const long long most = srhip_div_up(h, 32);
+        if (want > most) want = most;
+        if (want < 1) want = 1;
+        sp.seg_h = srhip_div_up(h, want);
+        sp.segs = srhip_div_up(h, sp.seg_h);
+        sp.strips = strips;
+        const long long units = (long long)planes * strips * sp.segs;
+        // (the partials of the streaming form: one pair per work-group; the workspace holds one per 32 x 32 tile, never fewer)
+        SRHIP_REQUIRE(units <= nblocks, "l1_ssim_loss: internal: more segments than tile partials");
+        sp.nunits = (int)units;
+        sp.p = p;
+        const unsigned sgrid = (unsigned)((units + 7) / 8 * 8);
+        hipLaunchKernelGGL(ssim_fwd_stream_kernel, dim3(sgrid), dim3(SW), 0, s, sp);
+        int rcs = srhip_check_launch("ssim_fwd_stream_kernel");
+        if (rcs != SRHIP_OK) return rcs;
+        hipLaunchKernelGGL(ssim_bwd_stream_kernel, dim3(sgrid), dim3(SW), 0, s, sp);
+        rcs = srhip_check_launch("ssim_bwd_stream_kernel");
+        if (rcs != SRHIP_OK) return rcs;
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, p.partial, (int)units, (float)(1.0 / n), lambda_l1,
+                           lambda_ssim, out3);
+        return srhip_check_launch("loss_finalize_kernel");
+    }
     const unsigned grid = (unsigned)((nblocks + 7) / 8 * 8);
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(grid), dim3(256), 0, s, p);
     int rc = srhip_check_launch("ssim_fwd_kernel");

@@ -40,7 +40,7 @@ def test_no_compiler_formed_packed_fp32_in_the_vector_alu_kernels(tmp_path):
     assert len(flagged) == 1
     for obj in ("memops.o", "loss.o", "conv_direct.o", "conv3x3_mfma.o", "conv3x3_pair.o", "conv_gemm.o", "conv1x1_chain.o", "conv3x3_wgrad.o"):
         assert obj in flagged[0], obj
-    allowed = ("upsample_int_nhwc_kernel", "layernorm_cf", "ssim_fwd_kernel", "ssim_bwd_kernel")
+    allowed = ("upsample_int_nhwc_kernel", "layernorm_cf", "ssim_fwd_kernel", "ssim_bwd_kernel", "ssim_fwd_stream_kernel", "ssim_bwd_stream_kernel")
 
     def packed_by_kernel(name, extra):
         out = tmp_path / (name + ".s")

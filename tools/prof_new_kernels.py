@@ -2,6 +2,7 @@
 """A few launches of one of the kernels added last (for rocprofv3 counter passes):
     rocprofv3 --pmc <counters> -- python3 tools/prof_new_kernels.py <case>
 cases: chain (160-160-160-64 1x1 chain at 544x960), chain_res (112-64-64-64 + residual), esa (ESA tail at 540x960 x 48),
+loss (fused clip + L1 + SSIM forward and backward at 16 x 3 x 1024 x 1024), upbwd (x4 up-sampling backward at 16 x 1024 x 1024 x 32),
 pairbwd (both data gradients of an SRResidualBlock at 16 x 1024 x 1024), pairbits (the forward launch that emits the bits)."""
 import os
 import sys
@@ -21,6 +22,18 @@ if case in ("chain", "chain_res"):
     res = rnd(1, 544, 960, 64).to(torch.bfloat16) if case == "chain_res" else None
     for _ in range(REP):
         F_.conv1x1_chain(x, layers, alpha=0.45 if res is not None else 1.0, res=res)
+elif case == "loss":
+    from superresolution_amd.loss import FusedLossGroup
+    sr = (torch.rand(16, 3, 1024, 1024, device=dev, generator=g) * 1.2 - 0.1).requires_grad_(True)
+    hr = torch.rand(16, 3, 1024, 1024, device=dev, generator=g)
+    lg = FusedLossGroup(1.0, 0.5, clip=(0.0, 10.0))
+    for _ in range(REP):
+        loss, _ = lg({"hr_frames": hr, "sr_frames": sr})
+elif case == "upbwd":
+    dy = rnd(16, 1024, 1024, 32).to(torch.bfloat16)
+    y = torch.relu(rnd(16, 256, 256, 32)).to(torch.bfloat16)
+    for _ in range(REP):
+        F_.upsample_grid_bilinear_bwd_nhwc(dy, 256, 256, relu_out=y)
 elif case == "esa":
     x, c1, c3 = rnd(1, 540, 960, 48).to(torch.bfloat16), rnd(1, 540, 960, 16).to(torch.bfloat16), rnd(1, 88, 158, 16).to(torch.bfloat16)
     wf, w4 = rnd(16, 16) * 0.3, rnd(48, 16) * 0.3
