@@ -177,7 +177,8 @@ SRHIP_API int srhip_conv3x3_pair_fwd(const srhip_conv3x3_pair_args* args, void* 
  *               channels per pixel (so a channel slice of a wider tensor can be a source)
  *   wpack:      srhip_conv_gemm_pack_weights(weight (cout, cin, k, k) fp32, ..., cin_padded = sum of c[k]); input channel
  *               positions >= cin carry zero weights (channel padding of the last source)
- *   bias:       cout fp32 or NULL;  res: NULL or a tensor of dst's layout, added after activation and alpha
+ *   bias:       cout fp32 or NULL;  res: NULL or a tensor of dst's layout, added after activation and alpha (res_mode 0)
+ *               or used as a ReLU mask (res_mode 1)
  *   dst:        (n, ho, wo, cout_stride) bf16, ho = (h + 2 pad - k) / stride + 1; channels [0, pad16(cout)) are written
  *   alpha > 0;  act / slope as in srhip_conv3x3_args */
 typedef struct {
@@ -194,6 +195,8 @@ typedef struct {
     int ksize, stride, pad;
     int act;
     float slope, alpha;
+    int res_mode;        /* SRHIP_RES_ADD (0): + res;  SRHIP_RES_MASK (1): the result is zeroed where res <= 0 (the ReLU
+                            backward of the layer in front, whose output res is, on a data-gradient launch) */
 } srhip_conv_gemm_args;
 SRHIP_API size_t srhip_conv_gemm_packed_bytes(int cin_padded, int cout, int ksize);
 SRHIP_API int srhip_conv_gemm_pack_weights(const float* weight, void* packed, int cout, int cin, int ksize, int cin_padded,

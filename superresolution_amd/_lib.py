@@ -65,6 +65,7 @@ class ConvGemmArgs(ctypes.Structure):
         ("wpack", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("dst", c_void_p),
         ("n", c_int), ("h", c_int), ("w", c_int), ("cout", c_int), ("cout_stride", c_int),
         ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("act", c_int), ("slope", c_float), ("alpha", c_float),
+        ("res_mode", c_int),
     ]
 
 

@@ -248,48 +248,117 @@ class _ConvAuto(Function):
         w, y = ctx.saved_tensors[:2]
         srcs = ctx.saved_tensors[2:]
         stride, padding, act = ctx.cfg
-        cout, cin, k, _ = w.shape
         n, h, wd = srcs[0].shape[:3]
         dz = dy.contiguous() if y is None else F_.relu_mask(dy.contiguous(), y)
         dzs = dz if stride == 1 else _zero_insert2(dz, h, wd)         # gradient of the equivalent stride-1 layer
-        # ---- weight and bias gradient: the MFMA weight-gradient kernel per (<= 64 input, <= 64 output) channel slice
-        # pair; a 1x1 layer is the centre tap of the 3x3 result (a GEMM over a million pixels with a 160 x 160 output
-        # is a shape the GEMM library serves three times slower than that)
-        dw3 = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
-        db = torch.zeros((cout,), dtype=torch.float32, device=w.device)
-        # (the kernel reads the channel windows in place: no slice of x or dz is copied out)
-        dz_slices = [(o, min(64, cout - o)) for o in range(0, cout, 64)]
-        k0 = 0
-        for t in srcs:
-            for a in range(0, t.shape[-1], 64):
-                ci = min(a + 64, t.shape[-1]) - a
-                ci_real = min(ci, cin - (k0 + a))
-                if ci_real <= 0:
-                    continue
-                for o, co in dz_slices:
-                    # the bias gradient rides on the first input slice's launch (dz times ones on the MFMA pipe)
-                    F_.conv3x3_wgrad(t, dzs, dw3[o:o + co], db[o:o + co] if k0 + a == 0 else None, ci_real, co, ci_off=k0 + a,
-                                     x_window=(a, _tile_channels(ci)), dz_window=(o, _tile_channels(co)))
-            k0 += t.shape[-1]
-        dw = dw3 if k == 3 else dw3[:, :, 1:2, 1:2].contiguous()
-        # ---- data gradient, cut into the sources
+        dw, db = _auto_wgrad(srcs, dzs, w)
         dsrcs = [None] * len(srcs)
         if any(ctx.needs_input_grad[5:]):
-            wt = w.transpose(0, 1).flip(2, 3).contiguous() if k == 3 else w.transpose(0, 1).contiguous()
-            dx = F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2)        # (N,h,w,pad16(cin))
-            k0 = 0
-            for i, t in enumerate(srcs):
-                c = t.shape[-1]
-                if ctx.needs_input_grad[5 + i]:
-                    if k0 == 0 and dx.shape[-1] == c:
-                        dsrcs[i] = dx
-                    else:
-                        d = torch.zeros_like(t)
-                        hi = min(k0 + c, dx.shape[-1])
-                        d[..., :hi - k0] = dx[..., k0:hi]
-                        dsrcs[i] = d
-                k0 += c
+            dsrcs = _split_sources(_auto_dgrad(dzs, w), srcs, w.shape[1], ctx.needs_input_grad[5:])
         return (dw, db, None, None, None) + tuple(dsrcs)
+
+
+def _auto_wgrad(srcs, dzs: Tensor, w: Tensor):
+    """Weight and bias gradient of a layer of ``_ConvAuto`` from the gradient of its (equivalent stride-1) pre-activation:
+    the MFMA weight-gradient kernel per (<= 64 input, <= 64 output) channel slice pair; a 1x1 layer is the centre tap of
+    the 3x3 result (a GEMM over a million pixels with a 160 x 160 output is a shape the GEMM library serves three times
+    slower than that).  The kernel reads the channel windows in place: no slice of x or dz is copied out."""
+    cout, cin, k, _ = w.shape
+    dw3 = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
+    db = torch.zeros((cout,), dtype=torch.float32, device=w.device)
+    dz_slices = [(o, min(64, cout - o)) for o in range(0, cout, 64)]
+    k0 = 0
+    for t in srcs:
+        for a in range(0, t.shape[-1], 64):
+            ci = min(a + 64, t.shape[-1]) - a
+            ci_real = min(ci, cin - (k0 + a))
+            if ci_real <= 0:
+                continue
+            for o, co in dz_slices:
+                # the bias gradient rides on the first input slice's launch (dz times ones on the MFMA pipe)
+                F_.conv3x3_wgrad(t, dzs, dw3[o:o + co], db[o:o + co] if k0 + a == 0 else None, ci_real, co, ci_off=k0 + a,
+                                 x_window=(a, _tile_channels(ci)), dz_window=(o, _tile_channels(co)))
+        k0 += t.shape[-1]
+    return (dw3 if k == 3 else dw3[:, :, 1:2, 1:2].contiguous()), db
+
+
+def _auto_dgrad(dzs: Tensor, w: Tensor, mask: Tensor = None) -> Tensor:
+    """Data gradient w.r.t. the concatenated input: the same operator on transposed (3x3: flipped) weights; ``mask`` (the
+    ReLU output of the layer in front) is applied by the launch's epilogue."""
+    k = w.shape[-1]
+    wt = w.transpose(0, 1).flip(2, 3).contiguous() if k == 3 else w.transpose(0, 1).contiguous()
+    if mask is None:
+        return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2)        # (N,h,w,pad16(cin))
+    return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2, res=mask, res_mode=F_.RES_MASK)
+
+
+def _split_sources(dx: Tensor, srcs, cin: int, needs):
+    """The gradient of a concatenated input cut into the sources' channel ranges."""
+    out, k0 = [None] * len(srcs), 0
+    for i, t in enumerate(srcs):
+        c = t.shape[-1]
+        if needs[i]:
+            if k0 == 0 and dx.shape[-1] == c:
+                out[i] = dx
+            else:
+                d = torch.zeros_like(t)
+                hi = min(k0 + c, dx.shape[-1])
+                d[..., :hi - k0] = dx[..., k0:hi]
+                out[i] = d
+        k0 += c
+    return out
+
+
+class _ConvReluChain(Function):
+    """y_i = relu(conv_i(y_{i-1}) + b_i), i = 1..n, as ONE autograd node; y_0 may be several maps read as their
+    concatenation.  The intermediate maps have no other consumer, so each intermediate ReLU backward rides on the
+    data-gradient launch of the layer behind it (mask epilogue) instead of a pass of its own: one mask pass per chain.
+    Same launches, same roundings as n ``_ConvAuto`` nodes (a mask only zeroes): gradients are bit-equal."""
+
+    @staticmethod
+    def forward(ctx, nsrc: int, cfgs, *tensors: Tensor):
+        srcs, wb = tensors[:nsrc], tensors[nsrc:]
+        ws = [w.detach().float().contiguous() for w in wb[0::2]]
+        ys, x = [], (tuple(srcs) if nsrc > 1 else srcs[0])
+        for w, b, (stride, padding) in zip(ws, wb[1::2], cfgs):
+            k = w.shape[-1]
+            if b is None or w.shape[-2] != k or k not in (1, 3) or padding != k // 2 or stride not in (1, 2):
+                raise ValueError("autograd_ops.conv_relu_chain: layers are kernel 1 or 3 with padding kernel // 2, stride 1 or 2, with bias")
+            x = F_.conv2d_auto(x, w, b.detach().float().contiguous(), stride=stride, padding=padding, act=F_.ACT_RELU)
+            ys.append(x)
+        ctx.save_for_backward(*srcs, *ys, *ws)
+        ctx.nsrc, ctx.cfgs = nsrc, tuple(cfgs)
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        nsrc, cfgs = ctx.nsrc, ctx.cfgs
+        n = len(cfgs)
+        saved = ctx.saved_tensors
+        srcs, ys, ws = saved[:nsrc], saved[nsrc:nsrc + n], saved[nsrc + n:]
+        grads = [None] * (2 * n)
+        dz = F_.relu_mask(dy.contiguous(), ys[n - 1])
+        dsrcs = [None] * nsrc
+        for i in range(n - 1, -1, -1):
+            w = ws[i]
+            inp = srcs if i == 0 else (ys[i - 1],)
+            h, wd = inp[0].shape[1:3]
+            dzs = dz if cfgs[i][0] == 1 else _zero_insert2(dz, h, wd)
+            grads[2 * i], grads[2 * i + 1] = _auto_wgrad(inp, dzs, w)
+            if i > 0:
+                dz = _auto_dgrad(dzs, w, mask=ys[i - 1])
+                if dz.shape[-1] != ys[i - 1].shape[-1]:
+                    dz = _split_sources(dz, (ys[i - 1],), w.shape[1], (True,))[0]
+            elif any(ctx.needs_input_grad[2:2 + nsrc]):
+                dsrcs = _split_sources(_auto_dgrad(dzs, w), srcs, w.shape[1], ctx.needs_input_grad[2:2 + nsrc])
+        return (None, None) + tuple(dsrcs) + tuple(grads)
+
+
+def conv_relu_chain(x, layers) -> Tensor:
+    """layers: [(weight, bias, stride, padding), ...], each followed by ReLU; x an NHWC bf16 map or a tuple of maps."""
+    srcs = tuple(x) if isinstance(x, (tuple, list)) else (x,)
+    flat = [t for (w, b, _, _) in layers for t in (w, b)]
+    return _ConvReluChain.apply(len(srcs), tuple((s, p) for (_, _, s, p) in layers), *srcs, *flat)
 
 
 def conv2d(x, weight: Tensor, bias: Tensor, stride: int = 1, padding: int = 1, act: int = F_.ACT_NONE) -> Tensor:

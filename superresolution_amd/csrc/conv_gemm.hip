@@ -64,6 +64,7 @@ struct GemmParams {
     unsigned units;    // work-groups that have work
     int groups;        // output-channel groups of NT tiles
     int vec16;         // dst pixel rows are 16-byte aligned: the epilogue goes through LDS to 16-byte pixel-major stores
+    int res_mask;      // res is a ReLU mask (result zeroed where res <= 0) instead of an addend
 };
 
 template <int KS, int S, int NT>
@@ -350,7 +351,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                         const uint2 r = *(const uint2*)(rp + c0 * 2);
                         const float rf[4] = {bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, rf[e]);   // one rounding, whatever the contraction mode
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = p.res_mask ? (rf[e] > 0.0f ? v[e] * p.alpha : 0.0f)
+                                              : __builtin_fmaf(v[e], p.alpha, rf[e]);   // one rounding, whatever the contraction mode
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                     const uint2 r = *(const uint2*)(rp + c0 * 2);
                     const float rf[4] = {bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], p.alpha, rf[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = p.res_mask ? (rf[e] > 0.0f ? v[e] * p.alpha : 0.0f) : __builtin_fmaf(v[e], p.alpha, rf[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
@@ -544,6 +547,9 @@ SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* a, void* stream)
     p.vec16 = ((size_t)a->dst % 16 == 0 && a->cout_stride % 8 == 0) ? 1 : 0;
     p.slope = a->act == SRHIP_ACT_NONE ? 1.0f : (a->act == SRHIP_ACT_RELU ? 0.0f : a->slope);
     p.alpha = a->alpha;
+    SRHIP_REQUIRE(a->res_mode == SRHIP_RES_ADD || a->res_mode == SRHIP_RES_MASK, "conv_gemm: res_mode %d (add or mask)", a->res_mode);
+    SRHIP_REQUIRE(a->res_mode == SRHIP_RES_ADD || a->res != nullptr, "conv_gemm: the mask form needs `res`");
+    p.res_mask = a->res_mode == SRHIP_RES_MASK ? 1 : 0;
     {
         const size_t wb = srhip_conv_gemm_packed_bytes(cin_pad, a->cout, a->ksize);
         SRHIP_REQUIRE(wb > 0 && wb < (1ull << 31), "conv_gemm: packed weights too large");

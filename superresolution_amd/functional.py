@@ -429,7 +429,7 @@ def _k_slices(cpad: int):
 
 def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 1,
                 act: int = ACT_NONE, slope: float = 0.0, res: Optional[torch.Tensor] = None,
-                alpha: float = 1.0) -> torch.Tensor:
+                alpha: float = 1.0, res_mode: int = RES_ADD) -> torch.Tensor:
     """alpha * act(nn.Conv2d(x)) + res on an NHWC bf16 tensor with any channel count.  A 3x3 / stride 1 / pad 1 layer with
     at most 64 input and output channels is one launch of the register-resident MFMA kernel; every other layer with kernel 1
     or 3, stride 1 or 2, padding 0 or 1 is ONE launch of the implicit-GEMM kernel (``conv_gemm``: fp32 accumulation over the
@@ -463,7 +463,7 @@ def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: i
                 raise ValueError("conv2d_auto: the sources' channels must add up to the layer's input channels")
             wp = _cached_pack(weight, ("gemm", cpad), lambda: conv_gemm_pack_weights(weight.detach().float().contiguous(), cpad))
             return conv_gemm(tuple(srcs), wp, None if bias is None else bias.detach(), cout, kh, stride=stride, padding=padding,
-                             act=act, slope=slope, alpha=alpha, res=res)
+                             act=act, slope=slope, alpha=alpha, res=res, res_mode=res_mode)
         srcs = [s[0][..., s[1]:s[1] + s[2]].contiguous() if is_window(s) else s for s in srcs]   # every other path: copies
     if len(srcs) > 1:
         if any(t.shape[:3] != srcs[0].shape[:3] for t in srcs) or sum(t.shape[-1] for t in srcs) - cin >= 16:
@@ -479,7 +479,11 @@ def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: i
     if gemm_ok and not one_native:
         wp = _cached_pack(weight, ("gemm", cpad), lambda: conv_gemm_pack_weights(weight.detach().float().contiguous(), cpad))
         return conv_gemm(tuple(srcs), wp, None if bias is None else bias.detach(), cout, kh, stride=stride, padding=padding,
-                         act=act, slope=slope, alpha=alpha, res=res)
+                         act=act, slope=slope, alpha=alpha, res=res, res_mode=res_mode)
+    if res_mode != RES_ADD and not (as3x3 and stride == 1 and len(srcs) == 1 and cpad <= 64 and cout <= 64):
+        # the mask form exists on the implicit-GEMM kernel and on the single register-resident launch; elsewhere: a pass
+        out = conv2d_auto(x, weight, bias, stride=stride, padding=padding, act=act, slope=slope, alpha=alpha)
+        return relu_mask(out, res)
     if not (as3x3 or as1x1) or (alpha != 1.0 and (cpad > 64 or cout > 64 or stride != 1)):
         xin = srcs[0]
         for t in srcs[1:]:
@@ -520,7 +524,7 @@ def conv2d_auto(x, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: i
             sl = None if (a == 0 and k1 - k0 == src.shape[-1]) else (a, k1 - k0)
             if i == 0:
                 conv3x3(src, wp, b, n, res=res if (fuse_res and last) else None, act=act if last else ACT_NONE, slope=slope,
-                        alpha=alpha, ca_slice=sl, out=out, out_off=off)
+                        alpha=alpha, ca_slice=sl, out=out, out_off=off, res_mode=res_mode if (fuse_res and last) else RES_ADD)
             else:
                 conv3x3(src, wp, None, n, res=out, res_mode=RES_PRE, act=act if last else ACT_NONE, slope=slope, ca_slice=sl,
                         out=out, out_off=off)
@@ -547,7 +551,7 @@ def conv_gemm_pack_weights(weight: torch.Tensor, cin_padded: int) -> torch.Tenso
 
 def conv_gemm(srcs, wpack: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ksize: int, stride: int = 1, padding: int = 0,
               act: int = ACT_NONE, slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, res_mode: int = RES_ADD) -> torch.Tensor:
     """alpha * act(conv_{k, stride, padding}(concat(srcs)) + bias) + res in ONE launch with fp32 accumulation over the whole
     reduction.  ``srcs``: one NHWC bf16 map or a tuple of up to three with equal (N,H,W), each a multiple of 16 channels wide
     (a source may be ``(tensor, first_channel, channels)`` to read a channel slice in place)."""
@@ -580,6 +584,7 @@ def conv_gemm(srcs, wpack: torch.Tensor, bias: Optional[torch.Tensor], cout: int
     a.wpack, a.bias, a.res, a.dst = wpack.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr()
     a.n, a.h, a.w, a.cout, a.cout_stride = n, h, w, cout, out.shape[3]
     a.ksize, a.stride, a.pad, a.act, a.slope, a.alpha = ksize, stride, padding, act, slope, alpha
+    a.res_mode = res_mode      # RES_MASK: `res` is the ReLU output in front of a data-gradient launch (zero where it is <= 0)
     check(lib.srhip_conv_gemm_fwd(a, _stream()))
     return out
 

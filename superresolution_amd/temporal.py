@@ -18,6 +18,7 @@ are ONE fused kernel (``functional.disocclusion``), the depth clamp (:40-46) ``f
 and the gated sum of the main stage (:422) ``functional.attention_fuse``.  The warp is
 ``tools_math.backward_warping`` (the reference's own helper raises for every input; see that module).
 """
+import os
 from typing import Tuple
 
 import torch
@@ -117,11 +118,35 @@ class TransConvActivation(nn.Sequential):
         return _rec(self, F_.conv_transpose2x2s2_auto(x, c.weight, c.bias, act=F_.ACT_RELU), c.weight.shape[1])
 
 
-def _run_seq(seq: nn.Sequential, x: Tensor, addend: Tensor = None) -> Tensor:
+def _run_layers(mods, x):
+    for m in mods:
+        x = m.run(x)
+    return x
+
+
+_CHAIN_TRAIN = os.environ.get("SRHIP_NO_TRAIN_CHAIN", "0") != "1"   # A/B switch of the chained training nodes
+
+
+def _run_seq(seq, x: Tensor, addend: Tensor = None) -> Tensor:
     """The layers of `seq` in order; `addend` (a skip connection, model_final.py:308-313) is added to the result: by the
     up-sampling pass itself where the sequence ends in one and no graph is recorded, by an add otherwise."""
     last = len(seq) - 1
-    for i, m in enumerate(seq):
+    mods = list(seq)
+    skip = 0
+    for i, m in enumerate(mods):
+        if skip:
+            skip -= 1
+            continue
+        if isinstance(m, ConvActivation) and torch.is_grad_enabled() and _TRACE is None and _CHAIN_TRAIN:
+            # training graph: a run of conv + ReLU layers whose intermediate maps nobody else reads is ONE autograd node
+            # (each intermediate ReLU backward rides on the data-gradient launch behind it); recorded passes keep the layers apart
+            run = [m]
+            while i + len(run) < len(mods) and isinstance(mods[i + len(run)], ConvActivation):
+                run.append(mods[i + len(run)])
+            if len(run) >= 2:
+                x = A_.conv_relu_chain(x, [(r[0].weight, r[0].bias, r[0].stride[0], r[0].padding[0]) for r in run])
+                skip = len(run) - 1
+                continue
         if isinstance(m, (ConvActivation, TransConvActivation)):
             x = m.run(x)
         elif isinstance(m, nn.Upsample):  # x2 bilinear, align_corners=True (model_final.py:281-289)
@@ -196,8 +221,8 @@ class GBuffersEncoder(nn.Module):
         if chain and len(self.conv_enhance) == 4 and F_.conv1x1_chain_supported(chans(self.conv_enhance), True):
             # ... and fmap + enhance_param * (the chain's result) on its last epilogue
             return F_.conv1x1_chain(self.conv_enhance[0].run(e), tail(self.conv_enhance), alpha=self._enhance_scale(), res=fmap), vmax
-        for m in list(self.conv_enhance)[:-1]:
-            e = m.run(e)
+        e = _run_seq(list(self.conv_enhance)[:-1], e) if (torch.is_grad_enabled() and _TRACE is None and _CHAIN_TRAIN) \
+            else _run_layers(list(self.conv_enhance)[:-1], e)
         last = self.conv_enhance[-1][0]
         if torch.is_grad_enabled():   # enhance_param is trained: the scale and the add stay visible to autograd
             y = _rec(self.conv_enhance[-1], A_.conv2d(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU), last.out_channels)

@@ -113,3 +113,20 @@ def test_conv_gemm_rejects_bad_arguments(F_):
     with pytest.raises(SrhipError):
         F_.conv_gemm(x, wp, None, 8, 3, padding=1, alpha=0.0)
 
+
+
+@pytest.mark.parametrize("case", [(160, 128, 3, 9, 21), (64, 64, 1, 7, 130), (384, 48, 3, 4, 5), (96, 24, 3, 6, 40)])
+def test_conv_gemm_mask_epilogue_equals_a_mask_pass(F_, case):
+    """res_mode = mask: the result is zeroed where `res` (the ReLU output in front of a data-gradient launch,
+    core/trainer.py:160 through nn.ReLU) is not positive -- bit-equal to the launch followed by relu_mask."""
+    cin, cout, k, h, w = case
+    g = torch.Generator().manual_seed(cin + cout)
+    x = _rand(g, 2, h, w, cin).cuda()
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).cuda()
+    wp = F_.conv_gemm_pack_weights(wt, cin)
+    y = torch.relu(_rand(g, 2, h, w, F_.pad16(cout))).cuda()
+    got = F_.conv_gemm(x, wp, None, cout, k, stride=1, padding=k // 2, res=y, res_mode=F_.RES_MASK, alpha=0.5)
+    ref = F_.relu_mask(F_.conv_gemm(x, wp, None, cout, k, stride=1, padding=k // 2, alpha=0.5), y)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert bool((got[y <= 0] == 0).all())

@@ -231,3 +231,23 @@ def test_x2_align_corners_resize_backward_is_the_adjoint(shape):
     yr.backward(dy.float().permute(0, 3, 1, 2))
     assert float((y.detach().float().permute(0, 3, 1, 2) - yr.detach()).abs().max()) <= 2.0 ** -8
     assert float((x.grad.float().permute(0, 3, 1, 2) - xr.grad).abs().max()) <= 2.0 ** -7 * float(xr.grad.abs().max())
+
+
+def test_chained_training_nodes_give_the_same_gradients_bit_for_bit(monkeypatch):
+    """Runs of conv + ReLU layers are one autograd node in the training graph: each intermediate ReLU backward rides on the
+    data-gradient launch behind it (mask epilogue of the implicit-GEMM / register-resident kernel) instead of a pass of
+    its own.  A mask only zeroes, so forward and every one of the 113 gradients equal the layer-by-layer graph's exactly
+    (which the bf16-storage oracle test above pins, in recorded passes)."""
+    from superresolution_amd import temporal
+    outs = []
+    for chained in (True, False):
+        monkeypatch.setattr(temporal, "_CHAIN_TRAIN", chained)
+        m, args, target, G = _model_and_inputs()
+        m.train()
+        sr, ew = m(*[a.clone() for a in args])
+        _loss(sr, ew, target, G).backward()
+        outs.append((sr.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert len(outs[0][1]) == 113
+    for name, g in outs[0][1].items():
+        assert torch.equal(g, outs[1][1][name]), name
