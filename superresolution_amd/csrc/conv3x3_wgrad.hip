@@ -454,17 +454,28 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
     }
     const int slots = srhip_num_cus();
     const int nstrips = srhip_div_up(p.w, C::TW);
+    // Segments per strip: the cost of a launch in row steps = rounds x (rows of a segment + halo + pipeline fill) + what
+    // its partial tiles cost.  Every work-group that runs writes 160 KB of partial sums and the reduction reads them back:
+    // about 31 us for a full grid (measured: 10 us of the gradient launch, 17-21 us of the reduction), i.e. 0.11 row steps
+    // of 1.1 us per work-group.  On the small maps of the temporal network and RepRFN's crops that term is larger than the
+    // arithmetic, and a grid of 64-128 work-groups is cheaper than one per CU.
     int best_segs = 1;
     double best_cost = 1e30;
-    for (int rounds = 1; rounds <= 16; ++rounds) {
-        int segs = (int)(((long long)rounds * slots) / ((long long)nstrips * p.n));
-        if (segs < 1) segs = 1;
-        if (segs > p.h) segs = p.h;
-        const int seg_h = srhip_div_up(p.h, segs);
-        segs = srhip_div_up(p.h, seg_h);
-        const long long items = (long long)segs * nstrips * p.n;
+    static const double pcost = [] { const char* e = getenv("SRHIP_WGRAD_PCOST"); return e ? atof(e) : 0.11; }();
+    const long long base_items = (long long)nstrips * p.n;
+    long long max_segs = (16ll * slots + base_items - 1) / base_items;
+    if (max_segs > p.h) max_segs = p.h;
+    if (max_segs < 1) max_segs = 1;
+    int last_seg_h = -1;
+    for (int want = 1; want <= (int)max_segs; ++want) {
+        const int seg_h = srhip_div_up(p.h, want);
+        if (seg_h == last_seg_h) continue;
+        last_seg_h = seg_h;
+        const int segs = srhip_div_up(p.h, seg_h);
+        const long long items = (long long)segs * base_items;
         const int r = srhip_div_up(items, slots);
-        const double cost = (double)r * (seg_h + 2 + 6.0);
+        const long long wgs = items < slots ? items : slots;
+        const double cost = (double)r * (seg_h + 2 + 6.0) + pcost * (double)wgs;
         if (cost < best_cost) { best_cost = cost; best_segs = segs; }
     }
     p.seg_h = srhip_div_up(p.h, best_segs);
