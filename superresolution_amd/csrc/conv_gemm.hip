@@ -16,9 +16,13 @@
 //     work-group stages in LDS the input window (((2-1)s + k) rows x ((128-1)s + k) pixels, rows and columns outside the
 //     image as zeros: buffer loads whose offset fails the bounds check) and the stage's weights for all k*k taps (1 KiB
 //     fragments already in MFMA operand order), then every wave runs k*k steps of (2 + NT fragment reads -> 2 NT MFMAs),
-//     the reads of step i + 1 requested before the MFMAs of step i with counted waits.  The next stage's global loads are
+//     the reads of step i + 1 requested before the MFMAs of step i with counted waits.  The next stage's window loads are
 //     issued in front of the MFMA section and held in registers, so L2 latency overlaps the matrix work; the second
 //     work-group of the CU covers the commit phase and the barriers.
+//   * The weights do not pass through registers: a fragment is one buffer LDS-DMA instruction (1 KiB, contiguous in the
+//     packed weights) into the weight buffer of the next stage's parity, issued beside the window loads.  (A 16-byte LDS
+//     store costs 13 cycles of the register-to-LDS path per wave instruction, a third of the rate of the reads: with the
+//     weights committed from registers the commit phase was a fifth of a 160 -> 128 launch.)
 //   * LDS image of the window: [row][chunk][plane][slot][16 B], plane = which 8 of the 16 channels (x pixel parity for
 //     stride 2): each half-wave's fragment read is 512 contiguous bytes, free of bank conflicts.
 //   * Work-groups walk XCD bands (unit = (g % 8) * ceil(units / 8) + g / 8, channel group fastest): input rows shared by
@@ -79,8 +83,8 @@ struct GCfg {
     static constexpr int XP1 = KR * PX * 2;                         // 16-byte pieces of the input window of ONE chunk
     static constexpr int NXP1 = (XP1 + NTHREADS - 1) / NTHREADS;    // per thread and chunk
     static constexpr int NXP = NXP1 * KSUB;
-    static constexpr int WPIECES = NSTEP * NT * 64;
-    static constexpr int NWP = (WPIECES + NTHREADS - 1) / NTHREADS;
+    static constexpr int WFRAGS = NSTEP * NT;                       // 1-KiB weight fragments per stage
+    static constexpr int NWP = (WFRAGS + 3) / 4;                    // LDS-DMA pieces per wave and stage
     // LDS image of the input window: [row][chunk][plane][slot][16 B].  A lane's fragment is the 16 bytes (8 channels) of
     // one pixel; lanes 0..31 of a wave read 32 consecutive output pixels, lanes 32..63 the other 8 channels of the same
     // pixels.  plane = which 8 channels (x pixel parity for stride 2), slot = pixel (pixel / 2 for stride 2), so each
@@ -89,13 +93,15 @@ struct GCfg {
     static constexpr int NPL = 2 * S;
     static constexpr int PSL = (PX + S - 1) / S;
     static constexpr int X_BYTES = KSUB * KR * NPL * PSL * 16;
-    static constexpr int STAGE_LDS = X_BYTES + NSTEP * NT * 1024;   // + [chunk][tap][tile][1 KiB]
+    static constexpr int W_BYTES = WFRAGS * 1024;                   // [chunk][tap][tile][1 KiB], two buffers (stage parity)
+    static constexpr int STAGE_LDS = X_BYTES + 2 * W_BYTES;
     // epilogue staging: per wave 64 pixels x (NT * 32 channels bf16 + 16 B padding), pixel-major
     static constexpr int OUT_ROWB = NT * 64 + 16;
     static constexpr int OUT_WAVE = 64 * OUT_ROWB;
     static constexpr int BIAS_OFF = STAGE_LDS > 4 * OUT_WAVE ? STAGE_LDS : 4 * OUT_WAVE;   // the group's NT * 32 biases (fp32)
     static constexpr int LDS_BYTES = BIAS_OFF + NT * 32 * 4;
-    static_assert(NSTEP * NT * 1024 < 65536, "weight fragments are addressed by the LDS instruction's 16-bit offset");
+    static_assert(W_BYTES < 65536, "weight fragments are addressed by the LDS instruction's 16-bit offset");
+    static_assert(2 * LDS_BYTES <= 160 * 1024 || (KS == 1 && S == 2), "two work-groups share a CU's LDS (the strided 1x1 form stages three rows of 64 channels: one work-group per CU)");
 };
 
 // loops whose index must be a compile-time constant from the start (register arrays stay registers)
@@ -187,16 +193,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
         const int plane = (rem & 1) * S + (S == 2 ? (px & 1) : 0), slot = S == 2 ? (px >> 1) : px;
         xlds[m] = (unsigned)(((ky * C::KSUB * C::NPL + plane) * C::PSL + slot) * 16);   // + sub * NPL * PSL * 16
     });
-    // per-thread pieces of the weight tile: offset inside one (tap, chunk) block of ct_total KiB, plus the tap's stride
+    // The stage's weights go global -> LDS by buffer LDS-DMA, 1 KiB (one MFMA fragment, already in operand order) per
+    // instruction: fragment f = (chunk, tap, tile) of the stage belongs to wave f % 4.  Per-lane source offset inside the
+    // packed weights (a tile the last group does not have fails the bounds check: zeros), constant over the stages.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     unsigned woff[C::NWP];
     int wsub[C::NWP];
     g_for<0, C::NWP>([&](auto m_c) {
         constexpr int m = decltype(m_c)::value;
-        const int q = tid + m * NTHREADS;
-        const int step = q / (NT * 64), r = q - step * (NT * 64);
+        const int f = wv + 4 * m;
+        const int step = f / NT, ct = f - step * NT;
         const int sub = step / C::T, tap = step - sub * C::T;
-        const bool ok = (q < C::WPIECES) & (r < nt * 64);
-        woff[m] = ok ? (unsigned)(((tap * p.kc_total + sub) * p.ct_total + ct0) * 1024 + r * 16) : kOobOff;
+        const bool ok = (f < C::WFRAGS) & (ct < nt);
+        woff[m] = ok ? (unsigned)(((tap * p.kc_total + sub) * p.ct_total + ct0 + ct) * 1024 + lane * 16) : kOobOff;
         wsub[m] = sub;
     });
     const __amdgpu_buffer_rsrc_t wsrd = gemm_rsrc(p.wpack, p.wbytes);
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     const int nsrc = p.nsrc, sc0 = p.src[0].c, sc1 = p.src[1].c;
     const int st0 = p.src[0].cstride, st1 = p.src[1].cstride, st2 = p.src[2].cstride;
     const int kc_total = p.kc_total, ct_total = p.ct_total;
-    uint4 xreg[C::NXP], wreg[C::NWP];
+    uint4 xreg[C::NXP];
 
     // wave w: output row yo + (w >> 1), pixels 64 (w & 1) .. + 63 of the strip as two MFMA pixel tiles; every weight
     // fragment read from LDS feeds two MFMAs
@@ -231,20 +240,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     const int nstage = (kc_total + C::KSUB - 1) / C::KSUB;
     const unsigned baddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem +
                            (unsigned)((((wrow * S * C::KSUB * 2 + hl) * S) * C::PSL + pl) * 16);
-    const unsigned aaddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(C::X_BYTES + lane * 16);
+    const unsigned aaddr0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(C::X_BYTES + lane * 16);
     for (int st = -1; st < nstage; ++st) {
         if (st >= 0) {
+            // this wave's weight fragments of stage st have landed in LDS (and its window pieces in registers); the
+            // barriers below publish them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();   // everyone is done reading the previous stage
             g_for<0, C::NXP>([&](auto m_c) {
                 constexpr int m = decltype(m_c)::value;
                 constexpr int sub = m / C::NXP1, m1 = m % C::NXP1;
                 const int q = tid + m1 * NTHREADS;
                 if (C::XP1 % NTHREADS == 0 || q < C::XP1) *(uint4*)(xt + xlds[m1] + sub * C::NPL * C::PSL * 16) = xreg[m];
-            });
-            g_for<0, C::NWP>([&](auto m_c) {
-                constexpr int m = decltype(m_c)::value;
-                const int q = tid + m * NTHREADS;
-                if (C::WPIECES % NTHREADS == 0 || q < C::WPIECES) *(uint4*)(wt + q * 16) = wreg[m];
             });
             __syncthreads();
         }
@@ -272,21 +279,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                     xreg[sub * C::NXP1 + m] = gemm_load16(xs, (live && xpix[m] >= 0) ? (unsigned)xpix[m] * cbytes + xhalf[m] : kOobOff, soff);
                 });
             });
+            // weights of stage st + 1 -> the buffer that stage st - 1 used (every wave is past this iteration's barriers)
             const unsigned wsoff = (unsigned)(ns * C::KSUB * ct_total) * 1024u;
 #if defined(GEMM_EXP) && (GEMM_EXP & 1)
             if (st < 0)
 #endif
-            g_for<0, C::NWP>([&](auto m_c) {
-                constexpr int m = decltype(m_c)::value;
-                const bool live = C::KSUB == 1 || ns * C::KSUB + wsub[m] < kc_total;
-                wreg[m] = gemm_load16(wsrd, live ? woff[m] : kOobOff, wsoff);
-            });
+            if (st + 1 < nstage) {
+                char* wdst = wt + ((st + 1) & 1) * C::W_BYTES + wv * 1024;
+                g_for<0, C::NWP>([&](auto m_c) {
+                    constexpr int m = decltype(m_c)::value;
+                    const bool live = C::KSUB == 1 || ns * C::KSUB + wsub[m] < kc_total;
+                    if (C::WFRAGS % 4 == 0 || wv + 4 * m < C::WFRAGS)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (__attribute__((address_space(3))) void*)(wdst + m * 4096), 16,
+                                                                 (int)(live ? woff[m] : kOobOff), (int)wsoff, 0, 0);
+                });
+            }
         }
         __builtin_amdgcn_sched_barrier(0);   // the loads above stay in front of the MFMA section
         if (st < 0) continue;
         // NSTEP steps of (2 pixel fragments + NT weight fragments -> 2 NT MFMAs); the fragments of step i + 1 are
         // requested before the MFMAs of step i, with counted waits
         bf16x8 af[2][NT], bq[2][2];
+        const unsigned aaddr = aaddr0 + (unsigned)((st & 1) * C::W_BYTES);
         g_for<0, C::NSTEP>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
             auto issue = [&](auto j_c) __attribute__((always_inline)) {
@@ -468,16 +482,20 @@ int launch_gemm(const GemmParams& p, hipStream_t stream)
     // Small images: fewer output tiles per work-group give more work-groups (each re-stages the input window, which the
     // XCD's L2 holds).  Measured at 68 x 120 and 136 x 240 (256 -> 256: 36 -> 28 us with one tile per group, 192 -> 192:
     // 45 -> 38 us with two); from about 400 work-groups on, the widest grouping wins again.
-    int maxnt = MAXNT;
+    // (stride 2: the staged window is 41 KB, and with two weight buffers of three tiles a work-group would take more than
+    // half of the CU's LDS)
+    int maxnt = S == 2 ? 2 : MAXNT;
     const long long tiles = (long long)srhip_div_up(p.wo, TPX) * srhip_div_up(p.ho, ROWS) * p.n;
     while (maxnt > (S == 2 ? 2 : 1) && tiles * srhip_div_up(p.ct_total, maxnt) < 400) --maxnt;
-    if (const char* e = getenv("SRHIP_GEMM_NT")) maxnt = atoi(e) >= 1 && atoi(e) <= MAXNT ? atoi(e) : MAXNT;   // timing experiments
+    if (const char* e = getenv("SRHIP_GEMM_NT")) maxnt = atoi(e) >= 1 && atoi(e) <= (S == 2 ? 2 : MAXNT) ? atoi(e) : maxnt;   // timing experiments
     const int groups = srhip_div_up(p.ct_total, maxnt);
     const int nt = srhip_div_up(p.ct_total, groups);
     switch (nt) {
     case 1: return launch_gemm_nt<KS, S, 1>(p, groups, stream);
     case 2: return launch_gemm_nt<KS, S, 2>(p, groups, stream);
-    default: return launch_gemm_nt<KS, S, 3>(p, groups, stream);
+    default:
+        if constexpr (S == 1) return launch_gemm_nt<KS, S, 3>(p, groups, stream);
+        else return launch_gemm_nt<KS, S, 2>(p, groups, stream);
     }
 }
 
