@@ -40,7 +40,6 @@
 namespace {
 
 constexpr int TPX = 128;    // output pixels per row of a work-group's tile
-constexpr int ROWS = 2;     // output rows per work-group
 constexpr int MAXNT = 3;    // most 32-channel output tiles per work-group (a template parameter of the kernel)
 constexpr int NTHREADS = 256;
 constexpr unsigned kOobOff = 0x80000000u;   // buffer offset that fails the bounds check: the load returns zeros
@@ -71,8 +70,14 @@ struct GemmParams {
     int res_mask;      // res is a ReLU mask (result zeroed where res <= 0) instead of an addend
 };
 
-template <int KS, int S, int NT>
+// ROWS = output rows per work-group: 2 (wave w: row w / 2, 64 pixels = two MFMA pixel tiles) or 4 (wave w: row w, all 128
+// pixels = four pixel tiles; 3x3 stride 1 layers on large images: a weight fragment feeds four MFMAs, the window is 6
+// rows for 4 instead of 4 for 2, and a stage holds twice the matrix work per barrier pair)
+template <int KS, int S, int NT, int ROWS_ = 2>
 struct GCfg {
+    static constexpr int ROWS = ROWS_;
+    static constexpr int NPT = ROWS == 2 ? 2 : 4;                   // MFMA pixel tiles per wave
+    static_assert(ROWS == 2 || (ROWS == 4 && KS == 3 && S == 1 && NT <= 2), "four-row tiles: 3x3 stride 1, at most 64 output channels per wave");
     static constexpr int T = KS * KS;
     // 16-channel chunks per LDS stage: 4 for 1x1 layers (64 channels), 1 for 3x3 (two for the narrow-output stride-1 layers,
     // whole 64-byte sectors per pixel, was slower: 0.295 vs 0.245 ms on the 160 -> 128 layer)
@@ -142,10 +147,10 @@ __device__ __forceinline__ uint4 gemm_load16(__amdgpu_buffer_rsrc_t r, unsigned 
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <int KS, int S, int NT>
+template <int KS, int S, int NT, int ROWS>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams p)
 {
-    using C = GCfg<KS, S, NT>;
+    using C = GCfg<KS, S, NT, ROWS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xt = smem;
     char* wt = smem + C::X_BYTES;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     // each), so work-group g takes unit (g % 8) * ceil(units / 8) + g / 8 and every XCD owns a contiguous band of rows:
     // the input rows that neighbouring output rows share, and the re-read of a tile's input by its channel groups, hit in
     // that XCD's L2 (with the natural order a 167 MB input was fetched as 506 MB and the loads' latency showed).
-    const int strips = (p.wo + TPX - 1) / TPX, rowpairs = (p.ho + ROWS - 1) / ROWS;
+    const int strips = (p.wo + TPX - 1) / TPX, rowpairs = (p.ho + ROWS - 1) / ROWS;   // (groups of ROWS output rows)
     const unsigned per = (p.units + 7u) >> 3;
     const unsigned unit = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (unit >= p.units) return;
@@ -221,16 +226,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
 
     // wave w: output row yo + (w >> 1), pixels 64 (w & 1) .. + 63 of the strip as two MFMA pixel tiles; every weight
     // fragment read from LDS feeds two MFMAs
-    f32x16 acc[2][NT];
+    f32x16 acc[C::NPT][NT];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+    for (int pt = 0; pt < C::NPT; ++pt)
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[pt][ct][r] = 0.0f;
 
-    const int wrow = wave >> 1;
-    const int pl = (wave & 1) * 64 + (lane & 31);   // this lane's first output pixel inside the strip (the second: + 32)
+    const int wrow = ROWS == 2 ? wave >> 1 : wave;
+    const int wpx0 = ROWS == 2 ? (wave & 1) * 64 : 0;   // the wave's first pixel inside the strip
+    const int pl = wpx0 + (lane & 31);              // this lane's first output pixel inside the strip (the others: + 32 each)
     const int hl = lane >> 5;                       // which 8 of the chunk's 16 channels this lane feeds
 
     // Iteration st (a stage = KSUB chunks): [commit stage st to LDS] -> issue the global loads of stage st + 1 -> MFMAs
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
         if (st < 0) continue;
         // NSTEP steps of (2 pixel fragments + NT weight fragments -> 2 NT MFMAs); the fragments of step i + 1 are
         // requested before the MFMAs of step i, with counted waits
-        bf16x8 af[2][NT], bq[2][2];
+        bf16x8 af[2][NT], bq[2][C::NPT];
         const unsigned aaddr = aaddr0 + (unsigned)((st & 1) * C::W_BYTES);
         g_for<0, C::NSTEP>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
@@ -307,8 +313,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                 constexpr int j = decltype(j_c)::value;
                 constexpr int sub = j / C::T, tap = j % C::T, ky = tap / KS, kx = tap % KS;
                 constexpr int boff = (((ky * C::KSUB + sub) * C::NPL + (S == 2 ? (kx & 1) : 0)) * C::PSL + (S == 2 ? (kx >> 1) : kx)) * 16;
-                bq[j & 1][0] = g_lds_read<boff>(baddr);
-                bq[j & 1][1] = g_lds_read<boff + 32 * 16>(baddr);
+                g_for<0, C::NPT>([&](auto pt_c) {
+                    constexpr int pt = decltype(pt_c)::value;
+                    bq[j & 1][pt] = g_lds_read<boff + pt * 32 * 16>(baddr);
+                });
                 g_for<0, NT>([&](auto ct_c) {
                     constexpr int ct = decltype(ct_c)::value;
                     af[j & 1][ct] = g_lds_read<(j * NT + ct) * 1024>(aaddr);
@@ -317,17 +325,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
             if constexpr (i == 0) issue(GInt<0>{});
             if constexpr (i + 1 < C::NSTEP) {
                 issue(GInt<i + 1>{});
-                g_lds_wait<NT + 2>();
+                g_lds_wait<NT + C::NPT>();
             } else {
                 g_lds_wait<0>();   // nothing stays in flight across the barrier
             }
-            SRHIP_LOAD_FENCE(bq[i & 1][0]);
-            SRHIP_LOAD_FENCE(bq[i & 1][1]);
+            g_for<0, C::NPT>([&](auto pt_c) { (void)&bq; SRHIP_LOAD_FENCE(bq[i & 1][decltype(pt_c)::value]); });   // (void)&: asm operands alone do not make a generic lambda capture
             g_for<0, NT>([&](auto ct_c) {
                 constexpr int ct = decltype(ct_c)::value;
                 SRHIP_LOAD_FENCE(af[i & 1][ct]);
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][0], acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][1], acc[1][ct], 0, 0, 0);
+                g_for<0, C::NPT>([&](auto pt_c) {
+                    constexpr int pt = decltype(pt_c)::value;
+                    acc[pt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][pt], acc[pt][ct], 0, 0, 0);
+                });
             });
         });
     }
@@ -341,9 +350,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
         // consecutive channels of a pixel.
         __syncthreads();   // every wave is done with the last stage's window and weights
         char* ow = smem + wave * C::OUT_WAVE;
+        // 64 pixels (two pixel tiles) at a time through the wave's own staging area: LDS operations of one wave run in
+        // order, so the second half's writes follow the first half's read-back
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int px = 32 * pt + (lane & 31);
+        for (int half = 0; half < C::NPT / 2; ++half) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pt = 2 * half + pp;
+            const int px = 32 * pp + (lane & 31);
             const int xo = xo0 + pl + 32 * pt;
             const long long opix = ((long long)img * p.ho + yrow) * p.wo + xo;
             const bool live = xo < p.wo && yrow < p.ho;
@@ -377,13 +391,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
             }
         }
         // (the wave reads back only what it wrote itself: no barrier)
-        if (yrow >= p.ho) return;
         constexpr int PPP = NT * 4;   // 16-byte pieces per pixel
+        if (yrow < p.ho) {
 #pragma unroll
         for (int j = 0; j < PPP; ++j) {
             const int i = lane + 64 * j;
             const int px = i / PPP, cg = i - px * PPP;
-            const int xo = xo0 + (wave & 1) * 64 + px;
+            const int xo = xo0 + wpx0 + 64 * half + px;
             const int c0 = ct0 * 32 + cg * 8;
             if (xo < p.wo && c0 < p.cout_w) {
                 const long long opix = ((long long)img * p.ho + yrow) * p.wo + xo;
@@ -393,11 +407,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
                 *(uint4*)(p.dst + (opix * p.cout_stride + c0) * 2) = *(const uint4*)(ow + px * C::OUT_ROWB + cg * 16);
             }
         }
+        }
+        }
         return;
     }
     if (yrow >= p.ho) return;
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
+    for (int pt = 0; pt < C::NPT; ++pt) {
         const int xo = xo0 + pl + 32 * pt;
         if (xo >= p.wo) continue;
         const long long opix = ((long long)img * p.ho + yrow) * p.wo + xo;
@@ -452,15 +468,15 @@ __global__ void gemm_pack_weights_kernel(const float* __restrict__ w, unsigned s
     out[idx] = f32_to_bf16_bits(v);
 }
 
-template <int KS, int S, int NT>
+template <int KS, int S, int NT, int ROWS = 2>
 int launch_gemm_nt(GemmParams p, int groups, hipStream_t stream)
 {
-    using C = GCfg<KS, S, NT>;
+    using C = GCfg<KS, S, NT, ROWS>;
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];
     const int dev = srhip_current_device();
     if (!configured_dev[dev].load(std::memory_order_acquire)) {
         if (C::LDS_BYTES > 48 * 1024 &&
-            hipFuncSetAttribute((const void*)conv_gemm_kernel<KS, S, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+            hipFuncSetAttribute((const void*)conv_gemm_kernel<KS, S, NT, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
             srhip_set_error("conv_gemm: cannot raise the dynamic LDS limit to %d", C::LDS_BYTES);
             return SRHIP_ERR_LAUNCH;
         }
@@ -470,7 +486,7 @@ int launch_gemm_nt(GemmParams p, int groups, hipStream_t stream)
     SRHIP_REQUIRE(units < (1ll << 30), "conv_gemm: too many work-groups");
     p.units = (unsigned)units;
     p.groups = groups;
-    hipLaunchKernelGGL((conv_gemm_kernel<KS, S, NT>), dim3((unsigned)((units + 7) / 8 * 8)), dim3(NTHREADS), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<KS, S, NT, ROWS>), dim3((unsigned)((units + 7) / 8 * 8)), dim3(NTHREADS), C::LDS_BYTES, stream, p);
     return srhip_check_launch("conv_gemm_kernel");
 }
 
@@ -484,8 +500,22 @@ int launch_gemm(const GemmParams& p, hipStream_t stream)
     // 45 -> 38 us with two); from about 400 work-groups on, the widest grouping wins again.
     // (stride 2: the staged window is 41 KB, and with two weight buffers of three tiles a work-group would take more than
     // half of the CU's LDS)
+    if constexpr (KS == 3 && S == 1) {
+        // Four-row tiles (at most two output tiles per wave: 128 accumulator registers beside the fragments) where they
+        // were measured faster: 5 output tiles on a large image, which the two-row form runs as groups of 3 + 2
+        // (160 -> 160 at 544 x 960: 340 -> 314 us; with 4 tiles, 2 + 2 either way, the two-row form is as fast or faster:
+        // 160 -> 128 223 / 220 us, 112 -> 112 151 / 157, 128 -> 64 91 / 98).  SRHIP_GEMM_ROWS4 = 1 / 0 forces / forbids it.
+        const char* e = getenv("SRHIP_GEMM_ROWS4");
+        const int groups4 = srhip_div_up(p.ct_total, 2);
+        const long long units4 = (long long)srhip_div_up(p.wo, TPX) * srhip_div_up(p.ho, 4) * p.n * groups4;
+        const bool use4 = e ? atoi(e) == 1 : (p.ct_total == 5 && units4 >= 1024);
+        if (use4) {
+            if (srhip_div_up(p.ct_total, groups4) == 1) return launch_gemm_nt<KS, S, 1, 4>(p, groups4, stream);
+            return launch_gemm_nt<KS, S, 2, 4>(p, groups4, stream);
+        }
+    }
     int maxnt = S == 2 ? 2 : MAXNT;
-    const long long tiles = (long long)srhip_div_up(p.wo, TPX) * srhip_div_up(p.ho, ROWS) * p.n;
+    const long long tiles = (long long)srhip_div_up(p.wo, TPX) * srhip_div_up(p.ho, 2) * p.n;
     while (maxnt > (S == 2 ? 2 : 1) && tiles * srhip_div_up(p.ct_total, maxnt) < 400) --maxnt;
     if (const char* e = getenv("SRHIP_GEMM_NT")) maxnt = atoi(e) >= 1 && atoi(e) <= (S == 2 ? 2 : MAXNT) ? atoi(e) : maxnt;   // timing experiments
     const int groups = srhip_div_up(p.ct_total, maxnt);

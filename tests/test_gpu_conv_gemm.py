@@ -130,3 +130,22 @@ def test_conv_gemm_mask_epilogue_equals_a_mask_pass(F_, case):
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
     assert bool((got[y <= 0] == 0).all())
+
+
+@pytest.mark.parametrize("case", [(160, 160, 9, 200, 1), (64, 40, 7, 130, 2), (96, 128, 6, 21, 1), (48, 24, 5, 300, 1)])
+def test_conv_gemm_four_row_tiles_equal_two_row_tiles(F_, case, monkeypatch):
+    """The four-row work-group tile (large images with 5 output tiles by default) runs the same reduction in the same order
+    as the two-row tile: bit-equal results, including rows past the image's last (h not a multiple of 4)."""
+    cin, cout, h, w, n = case
+    g = torch.Generator().manual_seed(cin * cout)
+    x = _rand(g, n, h, w, cin).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    wp = F_.conv_gemm_pack_weights(wt, cin)
+    res = _rand(g, n, h, w, F_.pad16(cout)).cuda()
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("SRHIP_GEMM_ROWS4", force)
+        outs.append(F_.conv_gemm(x, wp, b, cout, 3, stride=1, padding=1, act=F_.ACT_LRELU, slope=0.1, alpha=0.5, res=res))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
