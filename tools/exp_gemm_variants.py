@@ -14,13 +14,11 @@ OUT = os.path.join(ROOT, "superresolution_amd", "_exp")
 
 BAR = [("            __syncthreads();   // everyone is done reading the previous stage\n", ""),
        ("            });\n            __syncthreads();\n        }\n        {", "            });\n        }\n        {")]
-COMMIT = [("if (C::XP1 % NTHREADS == 0 || q < C::XP1) *(uint4*)", "if (tid < 0) *(uint4*)"),
-          ("if (C::WPIECES % NTHREADS == 0 || q < C::WPIECES) *(uint4*)", "if (tid < 0) *(uint4*)")]
-FRAG = [("                bq[j & 1][0] = g_lds_read<boff>(baddr);\n                bq[j & 1][1] = g_lds_read<boff + 32 * 16>(baddr);", ""),
+COMMIT = [("if (C::XP1 % NTHREADS == 0 || q < C::XP1) *(uint4*)", "if (tid < 0) *(uint4*)")]
+FRAG = [("                    bq[j & 1][pt] = g_lds_read<boff + pt * 32 * 16>(baddr);", ""),
         ("                    af[j & 1][ct] = g_lds_read<(j * NT + ct) * 1024>(aaddr);", "")]
-MFMA = [("                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][0], acc[0][ct], 0, 0, 0);\n"
-         "                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][1], acc[1][ct], 0, 0, 0);",
-         "                acc[0][ct][0] += (float)af[i & 1][ct][0] + (float)bq[i & 1][0][0]; acc[1][ct][0] += (float)bq[i & 1][1][0];")]
+MFMA = [("                    acc[pt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][ct], bq[i & 1][pt], acc[pt][ct], 0, 0, 0);",
+         "                    acc[pt][ct][0] += (float)af[i & 1][ct][0] + (float)bq[i & 1][pt][0];")]
 
 VARIANTS = {
     "base": ([], 0),
