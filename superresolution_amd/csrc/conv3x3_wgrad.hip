@@ -359,60 +359,60 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
 
 // Sums the partial tiles in a fixed order and scatters them into the fp32 OIHW gradient.
 // Accumulator register r of lane l holds row (r&3) + 8(r>>2) + 4(l>>5) (= co) and column l&31 (= ci).
-// A block of 256 threads = 8 thread groups x 32 lanes; every group sums every 8th partial, then the 8 sums are added
-// in a fixed order.  Blocks below nvec_blocks reduce weight elements, four consecutive input channels per lane (one
-// 16-byte load per partial; 512 contiguous bytes per group); the blocks behind them reduce the bias gradient, one
-// element per lane.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cit_n, int nt,
-                                                           float* __restrict__ dw, int w_i, int ci_off, int ci_real,
-                                                           int co_real, int ci_pad32, float* __restrict__ db,
-                                                           int accumulate, float scale, int nvec_blocks)
+// A partial tile of one tap is 4 KiB contiguous ([16 registers][64 lanes]).  A weight block = (output tile, tap, quarter q of
+// the tile = registers 4q..4q+3 = rows 8q..8q+7): 16 thread groups of 64 lanes, group g sums partials g, g+16, ..., every
+// lane one float4 of the quarter's contiguous 1 KiB (a 41 MB workspace read in 1-KiB pieces; as 128-byte runs, one per
+// (co, tap, 32 ci), the same sum ran at 1.4 TB/s), then the 16 sums are added in a fixed order.  The blocks behind the
+// weight blocks reduce the bias gradient, one element per lane (32 groups of 32 lanes).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cit_n, int nt,
+                                                            float* __restrict__ dw, int w_i, int ci_off, int ci_real,
+                                                            int co_real, float* __restrict__ db, int accumulate,
+                                                            float scale, int nwblocks)
 {
-    __shared__ float4 red[8][32];
-    const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int nw = co_real * 9 * ci_pad32;
+    __shared__ float4 red[16][64];
     const int ks = 4 / nt;
     const int total = nwg * ks;
-    if ((int)blockIdx.x < nvec_blocks) {
-        const int idx = ((int)blockIdx.x * 32 + o) * 4;
-        int tile = 0, elem = -1, ci = 0, co = 0, tap = 0;
-        if (idx < nw) {
-            ci = idx % ci_pad32;
-            tap = (idx / ci_pad32) % 9;
-            co = idx / (ci_pad32 * 9);
-            if (ci < ci_real) {
-                const int m = co & 31;
-                tile = (co >> 5) * cit_n + (ci >> 5);
-                elem = tap * 1024 + ((m & 3) + 4 * (m >> 3)) * 64 + (ci & 31) + 32 * ((m >> 2) & 1);
-            }
-        }
+    if ((int)blockIdx.x < nwblocks) {
+        int b = (int)blockIdx.x;
+        const int q = b & 3; b >>= 2;
+        const int tap = b % 9, tile = b / 9;
+        const int cot = tile / cit_n, cit = tile - cot * cit_n;
+        if (32 * cot + 8 * q >= co_real) return;   // the quarter's rows are all padding (uniform over the block)
+        const int l64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+        const int r = 4 * q + (l64 >> 4), l0 = (l64 & 15) * 4;
+        const int ci0 = 32 * cit + (l0 & 31);
+        const int co = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * (l0 >> 5);
+        const bool live = ci0 < ci_real && co < co_real;
         float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (elem >= 0) {
+        if (live) {
+            const float* src = partial + (size_t)tap * 1024 + r * 64 + l0;
 #pragma unroll 8
-            for (int k = part; k < total; k += 8) {   // unrolled: eight loads in flight, added in the same order
+            for (int k = grp; k < total; k += 16) {   // unrolled: eight loads in flight, added in the same order
                 const int wg = k / ks, wv = tile + (k % ks) * nt;
-                const float4 v = *(const float4*)(partial + (size_t)(wg * 4 + wv) * 10240 + elem);
+                const float4 v = *(const float4*)(src + (size_t)(wg * 4 + wv) * 10240);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
         }
-        red[part][o] = s;
+        red[grp][l64] = s;
         __syncthreads();
-        if (part == 0 && elem >= 0) {
-            float4 t = red[0][o];
+        if (grp == 0 && live) {
+            float4 t = red[0][l64];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) { const float4 r = red[k][o]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+            for (int k = 1; k < 16; ++k) { const float4 v = red[k][l64]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
             const float tv[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (ci + j < ci_real) {
-                    float* dst = dw + ((size_t)co * w_i + ci_off + ci + j) * 9 + tap;
+                if (ci0 + j < ci_real) {
+                    float* dst = dw + ((size_t)co * w_i + ci_off + ci0 + j) * 9 + tap;
                     *dst = accumulate ? *dst + tv[j] : tv[j];
                 }
         }
         return;
     }
     // bias gradient: the dz x ones accumulators of the waves of each co tile (every ci tile holds a share)
-    const int co = ((int)blockIdx.x - nvec_blocks) * 32 + o;
+    float* redb = (float*)red;   // [32 groups][32 lanes]
+    const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int co = ((int)blockIdx.x - nwblocks) * 32 + o;
     int tile = 0, elem = -1;
     if (db != nullptr && co < co_real) {
         const int m = co & 31;
@@ -421,17 +421,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     float sb = 0.0f;
     if (elem >= 0) {
-        for (int k = part; k < total; k += 8) {
+        for (int k = part; k < total; k += 32) {
             const int wg = k / ks, wv = tile + (k % ks) * nt;
             for (int c = 0; c < cit_n; ++c) sb += partial[(size_t)(wg * 4 + wv + c) * 10240 + elem];
         }
     }
-    red[part][o].x = sb;
+    redb[part * 32 + o] = sb;
     __syncthreads();
     if (part == 0 && elem >= 0) {
-        float t = red[0][o].x;
+        float t = redb[o];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][o].x;
+        for (int k = 1; k < 32; ++k) t += redb[k * 32 + o];
         t *= scale;
         db[co] = accumulate ? db[co] + t : t;
     }
@@ -488,11 +488,10 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<C>, dim3(grid), dim3(C::NWAVES * 64), C::LDS_BYTES, stream, p);
     int rc = srhip_check_launch("conv3x3_wgrad_kernel");
     if (rc != SRHIP_OK) return rc;
-    const int ci_pad32 = (ci_real + 31) / 32 * 32;
-    const int nvec_blocks = srhip_div_up(co_real * 9 * ci_pad32, 128);
+    const int nwblocks = C::NT * 9 * 4;
     const int nbias_blocks = db != nullptr ? srhip_div_up(co_real, 32) : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nvec_blocks + nbias_blocks), dim3(256), 0, stream, p.partial, grid,
-                       C::CIT, C::NT, dw, w_i, ci_off, ci_real, co_real, ci_pad32, db, accumulate, scale, nvec_blocks);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nwblocks + nbias_blocks), dim3(1024), 0, stream, p.partial, grid, C::CIT,
+                       C::NT, dw, w_i, ci_off, ci_real, co_real, db, accumulate, scale, nwblocks);
     return srhip_check_launch("wgrad_reduce_kernel");
 }
 

@@ -13,7 +13,8 @@ from superresolution_amd import functional as F_  # noqa: E402
 CASES = {"wide": (160, 128, 3, 1, 544, 960), "k1": (160, 160, 1, 1, 544, 960), "deep": (256, 256, 3, 1, 68, 120),
          "s2": (64, 128, 3, 2, 544, 960), "mid": (128, 128, 3, 1, 272, 480), "q192": (192, 192, 3, 1, 136, 240),
          "q384": (384, 256, 3, 1, 136, 240), "deep192": (256, 192, 3, 1, 68, 120), "s2q": (192, 256, 3, 2, 136, 240),
-         "wide160": (160, 160, 3, 1, 544, 960), "w112": (112, 112, 3, 1, 544, 960), "w128_64": (128, 64, 3, 1, 544, 960)}
+         "wide160": (160, 160, 3, 1, 544, 960), "w112": (112, 112, 3, 1, 544, 960), "w128_64": (128, 64, 3, 1, 544, 960),
+         "gate": (96, 2, 3, 1, 544, 960), "n96_64": (96, 64, 3, 1, 544, 960), "n128_48": (128, 48, 3, 1, 544, 960)}
 
 
 def main():
