@@ -455,13 +455,14 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
     const int slots = srhip_num_cus();
     const int nstrips = srhip_div_up(p.w, C::TW);
     // Segments per strip: the cost of a launch in row steps = rounds x (rows of a segment + halo + pipeline fill) + what
-    // its partial tiles cost.  Every work-group that runs writes 160 KB of partial sums and the reduction reads them back:
-    // about 31 us for a full grid (measured: 10 us of the gradient launch, 17-21 us of the reduction), i.e. 0.11 row steps
-    // of 1.1 us per work-group.  On the small maps of the temporal network and RepRFN's crops that term is larger than the
+    // its partial tiles cost.  Every work-group that runs writes 160 KB of partial sums and the reduction reads them back
+    // (about 10 us of the gradient launch and 10 us of the reduction for a full grid): a few hundredths of a 1.1 us row
+    // step per work-group; 0.06 measured best on the temporal network's training step (0.03-0.16 within 1 % of each other,
+    // no partial term at all 3 % slower).  On the small maps of that network and of RepRFN's crops the term outweighs the
     // arithmetic, and a grid of 64-128 work-groups is cheaper than one per CU.
     int best_segs = 1;
     double best_cost = 1e30;
-    static const double pcost = [] { const char* e = getenv("SRHIP_WGRAD_PCOST"); return e ? atof(e) : 0.11; }();
+    static const double pcost = [] { const char* e = getenv("SRHIP_WGRAD_PCOST"); return e ? atof(e) : 0.06; }();
     const long long base_items = (long long)nstrips * p.n;
     long long max_segs = (16ll * slots + base_items - 1) / base_items;
     if (max_segs > p.h) max_segs = p.h;
