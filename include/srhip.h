@@ -254,6 +254,24 @@ SRHIP_API int srhip_conv3x3_wgrad_windows(const void* x, const void* dz, float* 
                                           int co_pad, int co_real, int accumulate, float scale,
                                           int x_cstride, int x_coff, int dz_cstride, int dz_coff, void* stream);
 
+/* Several (input window, gradient window) pairs of ONE layer in one launch pair (gradient + reduction): the channel-slice
+ * pairs of a layer with more than 64 input or output channels (core/models/model_final.py:329-379 under loss.backward(),
+ * core/trainer.py:160) share image size, tile shape (ci_pad, co_pad) and the weight's input-channel count w_i.  Job j
+ * fills dw_j[co][ci_off + ci][ky][kx] for co < co_real, ci < ci_real, where dw_j points at the first output row of the
+ * job's output-channel slice inside the fp32 (O, w_i, 3, 3) gradient; db_j (or NULL) likewise.  1 <= njobs <= 32; the
+ * jobs' regions of dw must not overlap unless accumulate is set and the overlap is intended.  Same workspace as above. */
+typedef struct {
+    const void* x;        /* NHWC bf16 map that holds the input window */
+    const void* dz;       /* NHWC bf16 map that holds the gradient window */
+    float* dw;
+    float* db;            /* or NULL */
+    int ci_real, ci_off, co_real;
+    int x_cstride, x_coff, dz_cstride, dz_coff;   /* channels per pixel of the maps, first channel of the windows */
+    int reserved;         /* 0 */
+} srhip_wgrad_job;
+SRHIP_API int srhip_conv3x3_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w,
+                                        int ci_pad, int co_pad, int w_i, int accumulate, float scale, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Generic direct convolution (any kernel size / stride / padding, NHWC bf16,
  * fp32 accumulate on the vector ALU).  For the small memory-bound layers:

@@ -69,6 +69,15 @@ class ConvGemmArgs(ctypes.Structure):
     ]
 
 
+class WgradJob(ctypes.Structure):
+    """srhip_wgrad_job"""
+    _fields_ = [
+        ("x", c_void_p), ("dz", c_void_p), ("dw", c_void_p), ("db", c_void_p),
+        ("ci_real", c_int), ("ci_off", c_int), ("co_real", c_int),
+        ("x_cstride", c_int), ("x_coff", c_int), ("dz_cstride", c_int), ("dz_coff", c_int), ("reserved", c_int),
+    ]
+
+
 class Conv1x1ChainArgs(ctypes.Structure):
     """srhip_conv1x1_chain_args"""
     _fields_ = [
@@ -97,6 +106,7 @@ _SIGNATURES = {
     "srhip_conv3x3_wgrad_workspace_bytes": (c_size_t, []),
     "srhip_conv3x3_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float, c_void_p]),
     "srhip_conv3x3_wgrad_windows": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float] + [c_int] * 4 + [c_void_p]),
+    "srhip_conv3x3_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     "srhip_conv2d_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 +
                             [c_int, c_float, c_float, c_void_p]),
     "srhip_upsample_grid_bilinear_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

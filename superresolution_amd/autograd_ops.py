@@ -5,6 +5,7 @@ each is a torch.autograd.Function whose forward AND backward run on the HIP kern
 Activations are (N,H,W,C) bf16 tensors whose channel count is 16, 32 or 64 (the weight-gradient kernel's tile
 sizes): a 48-channel feature map travels padded to 64 channels, the pad channels staying exactly zero through
 every operator (zero weights, zero bias, LeakyReLU(0) = 0, x * sigmoid(.) = 0 for x = 0)."""
+import os
 from typing import Optional
 
 import torch
@@ -267,6 +268,9 @@ def _auto_wgrad(srcs, dzs: Tensor, w: Tensor):
     dw3 = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
     db = torch.zeros((cout,), dtype=torch.float32, device=w.device)
     dz_slices = [(o, min(64, cout - o)) for o in range(0, cout, 64)]
+    # all slice pairs of one tile shape go out together (one gradient launch + one reduction per group of <= 32 pairs
+    # instead of one each per pair: on the 1/4 and 1/8 resolution maps a pair is a few microseconds of matrix work)
+    groups = {}
     k0 = 0
     for t in srcs:
         for a in range(0, t.shape[-1], 64):
@@ -275,10 +279,14 @@ def _auto_wgrad(srcs, dzs: Tensor, w: Tensor):
             if ci_real <= 0:
                 continue
             for o, co in dz_slices:
-                # the bias gradient rides on the first input slice's launch (dz times ones on the MFMA pipe)
-                F_.conv3x3_wgrad(t, dzs, dw3[o:o + co], db[o:o + co] if k0 + a == 0 else None, ci_real, co, ci_off=k0 + a,
-                                 x_window=(a, _tile_channels(ci)), dz_window=(o, _tile_channels(co)))
+                # the bias gradient rides on the first input slice's job (dz times ones on the MFMA pipe)
+                groups.setdefault((_tile_channels(ci), _tile_channels(co)), []).append(
+                    (t, a, ci_real, k0 + a, dzs, o, co, o, k0 + a == 0))
         k0 += t.shape[-1]
+    batch = 1 if os.environ.get("SRHIP_NO_WGRAD_MULTI", "0") == "1" else F_.WGRAD_MAX_JOBS
+    for (ci_tile, co_tile), jobs in groups.items():
+        for b in range(0, len(jobs), batch):
+            F_.conv3x3_wgrad_multi(jobs[b:b + batch], dw3, db, ci_tile, co_tile)
     return (dw3 if k == 3 else dw3[:, :, 1:2, 1:2].contiguous()), db
 
 

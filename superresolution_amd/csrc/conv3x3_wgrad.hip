@@ -30,14 +30,36 @@
 
 namespace {
 
-struct WgradParams {
+// One launch serves up to kMaxJobs jobs = (input window, gradient window) pairs of ONE layer (same image size, same tile
+// shape): work-groups [j * wgs_per_job, (j + 1) * wgs_per_job) walk job j's work items.  The small maps of a wide layer
+// (384 -> 256 at 1/8 resolution = 24 channel-slice pairs of a few microseconds each) would otherwise pay a launch, a
+// pipeline fill, a full grid of partial tiles and a reduction per pair.
+constexpr int kMaxJobs = 32;
+struct WgradJob {
     const char* x;
     const char* dz;
+    // x and dz may be channel windows of wider maps: bytes per pixel of the map, byte offset of the window's first channel
+    int xs, xco, zs, zco;
+};
+struct WgradParams {
     float* partial;
     int n, h, w;
     int nstrips, nsegs, seg_h, total_items;
-    // x and dz may be channel windows of wider maps: bytes per pixel of the map, byte offset of the window's first channel
-    int xs, xco, zs, zco;
+    int njobs, wgs_per_job;
+    WgradJob jobs[kMaxJobs];
+};
+struct WgradOut {
+    float* dw;   // first output row of the job's co slice
+    float* db;   // or null
+    int ci_off, ci_real, co_real, pad;
+};
+struct ReduceParams {
+    const float* partial;
+    int nwg;              // work-groups (partial tile sets) per job
+    int cit_n, nt, w_i, accumulate;
+    float scale;
+    int nwblocks, blocks_per_job;
+    WgradOut out[kMaxJobs];
 };
 
 constexpr int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
@@ -176,7 +198,10 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
     asm volatile("" : "+v"(ones));  // opaque: stays in four registers instead of being rebuilt next to its (asm) consumer
     bf16x4 alo[3][C::NKS], ahi[3][C::NKS];   // dz fragments of the three newest rows
 
-    for (int item = blockIdx.x; item < p.total_items; item += gridDim.x) {
+    const int job = __builtin_amdgcn_readfirstlane((int)blockIdx.x / p.wgs_per_job);
+    const int first_item = (int)blockIdx.x - job * p.wgs_per_job;
+    const WgradJob jb = p.jobs[job];
+    for (int item = first_item; item < p.total_items; item += p.wgs_per_job) {
         const int strip = item % p.nstrips;
         const int tseg = item / p.nstrips;
         const int seg = tseg % p.nsegs;
@@ -186,12 +211,12 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
         const int y1 = min(y0 + p.seg_h, H);
         const int nout = y1 - y0;
 
-        const unsigned img_x = (unsigned)(H * W) * (unsigned)p.xs;
-        const unsigned img_z = (unsigned)(H * W) * (unsigned)p.zs;
+        const unsigned img_x = (unsigned)(H * W) * (unsigned)jb.xs;
+        const unsigned img_z = (unsigned)(H * W) * (unsigned)jb.zs;
         const __amdgpu_buffer_rsrc_t rsrc_x =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long long)n * img_x), 0, (int)img_x, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)(jb.x + (long long)n * img_x), 0, (int)img_x, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_z =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(p.dz + (long long)n * img_z), 0, (int)img_z, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)(jb.dz + (long long)n * img_z), 0, (int)img_z, 0x00020000);
 
         // per-lane source offsets of this wave's DMA pieces (constant over the strip)
         unsigned xoff[C::MAXPX], zoff[C::MAXPZ];
@@ -203,7 +228,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
             const int c = (C::XPB == 128) ? (s ^ (((px >> 1) & 1) << 2)) : s;
             const int col = x0 - 1 + px;
             const bool ok = col >= 0 && col < W && px < C::TW + 2;
-            xoff[m] = ok ? (unsigned)(col * p.xs + p.xco + c * 16) : kOob;
+            xoff[m] = ok ? (unsigned)(col * jb.xs + jb.xco + c * 16) : kOob;
         }
 #pragma unroll
         for (int m = 0; m < C::MAXPZ; ++m) {
@@ -212,16 +237,16 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
             const int px = L / CPP, s = L % CPP;
             const int c = (C::ZPB == 128) ? (s ^ (((px >> 1) & 1) << 2)) : s;
             const int col = x0 + px;
-            zoff[m] = col < W ? (unsigned)(col * p.zs + p.zco + c * 16) : kOob;
+            zoff[m] = col < W ? (unsigned)(col * jb.zs + jb.zco + c * 16) : kOob;
         }
         // x row r <-> image row y0 - 1 + r (r = 0 .. nout+1); dz row r <-> image row y0 + r.
         // Piece m (0 .. MAXPX+MAXPZ-1) of a row pair: x pieces first, then dz pieces; branch-free.
         auto x_soff = [&](const int r) {
             const int y = y0 - 1 + r;
             const bool in = (y >= 0) & (y < H) & (r < nout + 2);
-            return in ? (unsigned)(y * W) * (unsigned)p.xs : kOob;
+            return in ? (unsigned)(y * W) * (unsigned)jb.xs : kOob;
         };
-        auto z_soff = [&](const int r) { return (r < nout) ? (unsigned)((y0 + r) * W) * (unsigned)p.zs : kOob; };
+        auto z_soff = [&](const int r) { return (r < nout) ? (unsigned)((y0 + r) * W) * (unsigned)jb.zs : kOob; };
         auto issue_piece = [&](auto m_c, const unsigned xsoff, const unsigned xslot, const unsigned zsoff, const unsigned zslot) {
             constexpr int m = decltype(m_c)::value;
             if constexpr (m < C::MAXPX) {
@@ -364,16 +389,21 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
 // lane one float4 of the quarter's contiguous 1 KiB (a 41 MB workspace read in 1-KiB pieces; as 128-byte runs, one per
 // (co, tap, 32 ci), the same sum ran at 1.4 TB/s), then the 16 sums are added in a fixed order.  The blocks behind the
 // weight blocks reduce the bias gradient, one element per lane (32 groups of 32 lanes).
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cit_n, int nt,
-                                                            float* __restrict__ dw, int w_i, int ci_off, int ci_real,
-                                                            int co_real, float* __restrict__ db, int accumulate,
-                                                            float scale, int nwblocks)
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const ReduceParams rp)
 {
     __shared__ float4 red[16][64];
+    const int job = (int)blockIdx.x / rp.blocks_per_job, jblock = (int)blockIdx.x - job * rp.blocks_per_job;
+    const WgradOut jo = rp.out[job];
+    const float* __restrict__ partial = rp.partial + (size_t)job * rp.nwg * 4 * 10240;
+    float* __restrict__ dw = jo.dw;
+    float* __restrict__ db = jo.db;
+    const int nwg = rp.nwg, cit_n = rp.cit_n, nt = rp.nt, w_i = rp.w_i, accumulate = rp.accumulate, nwblocks = rp.nwblocks;
+    const int ci_off = jo.ci_off, ci_real = jo.ci_real, co_real = jo.co_real;
+    const float scale = rp.scale;
     const int ks = 4 / nt;
     const int total = nwg * ks;
-    if ((int)blockIdx.x < nwblocks) {
-        int b = (int)blockIdx.x;
+    if (jblock < nwblocks) {
+        int b = jblock;
         const int q = b & 3; b >>= 2;
         const int tap = b % 9, tile = b / 9;
         const int cot = tile / cit_n, cit = tile - cot * cit_n;
@@ -412,7 +442,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     // bias gradient: the dz x ones accumulators of the waves of each co tile (every ci tile holds a share)
     float* redb = (float*)red;   // [32 groups][32 lanes]
     const int o = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int co = ((int)blockIdx.x - nwblocks) * 32 + o;
+    const int co = (jblock - nwblocks) * 32 + o;
     int tile = 0, elem = -1;
     if (db != nullptr && co < co_real) {
         const int m = co & 31;
@@ -438,8 +468,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 }
 
 template <class C>
-int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int ci_real, int co_real, int accumulate,
-                 float scale, hipStream_t stream)
+int launch_wgrad(WgradParams p, const WgradOut* outs, int w_i, int accumulate, float scale, hipStream_t stream)
 {
     static std::atomic<bool> configured_dev[kSrhipMaxDevices];   // per device
     const int dev = srhip_current_device();
@@ -452,7 +481,8 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
         }
         configured_dev[dev].store(true, std::memory_order_release);
     }
-    const int slots = srhip_num_cus();
+    // every job gets the same share of the CUs (and of the workspace, which holds one partial tile set per CU)
+    const int slots = srhip_num_cus() / p.njobs > 0 ? srhip_num_cus() / p.njobs : 1;
     const int nstrips = srhip_div_up(p.w, C::TW);
     // Segments per strip: the cost of a launch in row steps = rounds x (rows of a segment + halo + pipeline fill) + what
     // its partial tiles cost.  Every work-group that runs writes 160 KB of partial sums and the reduction reads them back
@@ -476,7 +506,7 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
         const long long items = (long long)segs * base_items;
         const int r = srhip_div_up(items, slots);
         const long long wgs = items < slots ? items : slots;
-        const double cost = (double)r * (seg_h + 2 + 6.0) + pcost * (double)wgs;
+        const double cost = (double)r * (seg_h + 2 + 6.0) + pcost * (double)wgs * p.njobs;
         if (cost < best_cost) { best_cost = cost; best_segs = segs; }
     }
     p.seg_h = srhip_div_up(p.h, best_segs);
@@ -485,14 +515,19 @@ int launch_wgrad(WgradParams p, float* dw, float* db, int w_i, int ci_off, int c
     const long long total = (long long)p.nsegs * nstrips * p.n;
     SRHIP_REQUIRE(total < (1ll << 30), "conv3x3_wgrad: too many work items");
     p.total_items = (int)total;
-    const int grid = (int)(total < slots ? total : slots);
+    p.wgs_per_job = (int)(total < slots ? total : slots);
+    const int grid = p.wgs_per_job * p.njobs;
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<C>, dim3(grid), dim3(C::NWAVES * 64), C::LDS_BYTES, stream, p);
     int rc = srhip_check_launch("conv3x3_wgrad_kernel");
     if (rc != SRHIP_OK) return rc;
-    const int nwblocks = C::NT * 9 * 4;
-    const int nbias_blocks = db != nullptr ? srhip_div_up(co_real, 32) : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nwblocks + nbias_blocks), dim3(1024), 0, stream, p.partial, grid, C::CIT,
-                       C::NT, dw, w_i, ci_off, ci_real, co_real, db, accumulate, scale, nwblocks);
+    ReduceParams rp;
+    rp.partial = p.partial;
+    rp.nwg = p.wgs_per_job;
+    rp.cit_n = C::CIT; rp.nt = C::NT; rp.w_i = w_i; rp.accumulate = accumulate; rp.scale = scale;
+    rp.nwblocks = C::NT * 9 * 4;
+    rp.blocks_per_job = rp.nwblocks + C::COT;   // + one bias block per 32 output channels
+    for (int j = 0; j < p.njobs; ++j) rp.out[j] = outs[j];
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rp.blocks_per_job * p.njobs), dim3(1024), 0, stream, rp);
     return srhip_check_launch("wgrad_reduce_kernel");
 }
 
@@ -505,29 +540,35 @@ SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void)
     return (size_t)srhip_num_cus() * 4 * 10 * 1024 * sizeof(float);
 }
 
-SRHIP_API int srhip_conv3x3_wgrad_windows(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,
-                                          int w, int ci_pad, int ci_real, int ci_off, int w_i, int co_pad, int co_real,
-                                          int accumulate, float scale, int x_cstride, int x_coff, int dz_cstride, int dz_coff,
-                                          void* stream)
+SRHIP_API int srhip_conv3x3_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w,
+                                        int ci_pad, int co_pad, int w_i, int accumulate, float scale, void* stream)
 {
-    SRHIP_REQUIRE(x && dz && dw && workspace, "conv3x3_wgrad: null pointer");
+    SRHIP_REQUIRE(jobs && workspace, "conv3x3_wgrad: null pointer");
+    SRHIP_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "conv3x3_wgrad: %d jobs (1 .. %d per call)", njobs, kMaxJobs);
     SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1, "conv3x3_wgrad: empty tensor");
-    SRHIP_REQUIRE(ci_real >= 1 && ci_real <= ci_pad && co_real >= 1 && co_real <= co_pad, "conv3x3_wgrad: real channels exceed padded");
-    SRHIP_REQUIRE(ci_off >= 0 && ci_off + ci_real <= w_i, "conv3x3_wgrad: input-channel window [%d,%d) outside the weight's %d", ci_off, ci_off + ci_real, w_i);
-    SRHIP_REQUIRE(x_cstride >= 8 && x_cstride % 8 == 0 && x_coff >= 0 && x_coff % 8 == 0 && x_coff + ci_real <= x_cstride,
-                  "conv3x3_wgrad: x window [%d,%d) outside the map's %d channels (offsets and widths in multiples of 8)", x_coff, x_coff + ci_real, x_cstride);
-    SRHIP_REQUIRE(dz_cstride >= 8 && dz_cstride % 8 == 0 && dz_coff >= 0 && dz_coff % 8 == 0 && dz_coff + co_real <= dz_cstride,
-                  "conv3x3_wgrad: dz window [%d,%d) outside the map's %d channels (offsets and widths in multiples of 8)", dz_coff, dz_coff + co_real, dz_cstride);
-    SRHIP_REQUIRE((long long)h * w * (x_cstride > dz_cstride ? x_cstride : dz_cstride) * 2 < (1ll << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
     WgradParams p;
-    p.x = (const char*)x;
-    p.dz = (const char*)dz;
+    WgradOut outs[kMaxJobs];
     p.partial = (float*)workspace;
     p.n = n; p.h = h; p.w = w;
-    p.xs = x_cstride * 2; p.xco = x_coff * 2; p.zs = dz_cstride * 2; p.zco = dz_coff * 2;
+    p.njobs = njobs;
+    for (int j = 0; j < njobs; ++j) {
+        const srhip_wgrad_job& a = jobs[j];
+        SRHIP_REQUIRE(a.x && a.dz && a.dw, "conv3x3_wgrad: null pointer (job %d)", j);
+        SRHIP_REQUIRE(a.ci_real >= 1 && a.ci_real <= ci_pad && a.co_real >= 1 && a.co_real <= co_pad, "conv3x3_wgrad: real channels exceed padded (job %d)", j);
+        SRHIP_REQUIRE(a.ci_off >= 0 && a.ci_off + a.ci_real <= w_i, "conv3x3_wgrad: input-channel window [%d,%d) outside the weight's %d", a.ci_off, a.ci_off + a.ci_real, w_i);
+        SRHIP_REQUIRE(a.x_cstride >= 8 && a.x_cstride % 8 == 0 && a.x_coff >= 0 && a.x_coff % 8 == 0 && a.x_coff + a.ci_real <= a.x_cstride,
+                      "conv3x3_wgrad: x window [%d,%d) outside the map's %d channels (offsets and widths in multiples of 8)", a.x_coff, a.x_coff + a.ci_real, a.x_cstride);
+        SRHIP_REQUIRE(a.dz_cstride >= 8 && a.dz_cstride % 8 == 0 && a.dz_coff >= 0 && a.dz_coff % 8 == 0 && a.dz_coff + a.co_real <= a.dz_cstride,
+                      "conv3x3_wgrad: dz window [%d,%d) outside the map's %d channels (offsets and widths in multiples of 8)", a.dz_coff, a.dz_coff + a.co_real, a.dz_cstride);
+        SRHIP_REQUIRE((long long)h * w * (a.x_cstride > a.dz_cstride ? a.x_cstride : a.dz_cstride) * 2 < (1ll << 31), "conv3x3_wgrad: image too large for 32-bit offsets");
+        p.jobs[j].x = (const char*)a.x; p.jobs[j].dz = (const char*)a.dz;
+        p.jobs[j].xs = a.x_cstride * 2; p.jobs[j].xco = a.x_coff * 2; p.jobs[j].zs = a.dz_cstride * 2; p.jobs[j].zco = a.dz_coff * 2;
+        outs[j].dw = a.dw; outs[j].db = a.db; outs[j].ci_off = a.ci_off; outs[j].ci_real = a.ci_real; outs[j].co_real = a.co_real; outs[j].pad = 0;
+    }
+    for (int j = njobs; j < kMaxJobs; ++j) { p.jobs[j] = p.jobs[0]; }
     hipStream_t s = (hipStream_t)stream;
 #define SRHIP_WGRAD_CASE(CI, CO) \
-    if (ci_pad == CI && co_pad == CO) return launch_wgrad<WCfg<CI, CO>>(p, dw, db, w_i, ci_off, ci_real, co_real, accumulate, scale, s);
+    if (ci_pad == CI && co_pad == CO) return launch_wgrad<WCfg<CI, CO>>(p, outs, w_i, accumulate, scale, s);
     SRHIP_WGRAD_CASE(64, 64)
     SRHIP_WGRAD_CASE(32, 64)
     SRHIP_WGRAD_CASE(16, 64)
@@ -540,6 +581,19 @@ SRHIP_API int srhip_conv3x3_wgrad_windows(const void* x, const void* dz, float* 
 #undef SRHIP_WGRAD_CASE
     srhip_set_error("conv3x3_wgrad: unsupported padded channels ci=%d co=%d (each must be 16, 32 or 64)", ci_pad, co_pad);
     return SRHIP_ERR_INVALID;
+}
+
+SRHIP_API int srhip_conv3x3_wgrad_windows(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,
+                                          int w, int ci_pad, int ci_real, int ci_off, int w_i, int co_pad, int co_real,
+                                          int accumulate, float scale, int x_cstride, int x_coff, int dz_cstride, int dz_coff,
+                                          void* stream)
+{
+    srhip_wgrad_job job;
+    job.x = x; job.dz = dz; job.dw = dw; job.db = db;
+    job.ci_real = ci_real; job.ci_off = ci_off; job.co_real = co_real;
+    job.x_cstride = x_cstride; job.x_coff = x_coff; job.dz_cstride = dz_cstride; job.dz_coff = dz_coff;
+    job.reserved = 0;
+    return srhip_conv3x3_wgrad_multi(&job, 1, workspace, n, h, w, ci_pad, co_pad, w_i, accumulate, scale, stream);
 }
 
 SRHIP_API int srhip_conv3x3_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,

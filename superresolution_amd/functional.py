@@ -308,6 +308,46 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, dw: torch.Tensor, db: Optio
                                           ci_pad, xo, dz.shape[3], zo, _stream()))
 
 
+WGRAD_MAX_JOBS = 32
+
+
+def conv3x3_wgrad_multi(jobs, dw: torch.Tensor, db: Optional[torch.Tensor], ci_tile: int, co_tile: int,
+                        accumulate: bool = False, scale: float = 1.0) -> None:
+    """Several channel-slice pairs of ONE layer in one launch pair (srhip_conv3x3_wgrad_multi).  jobs: up to 32 tuples
+    (x, x_first_channel, ci_real, ci_off, dz, dz_first_channel, co_real, co_off, with_bias): job j fills
+    dw[co_off : co_off + co_real, ci_off : ci_off + ci_real] from channels [x_first_channel, + ci_tile) of the map x and
+    [dz_first_channel, + co_tile) of the map dz (tiles 16, 32 or 64; a window may reach past its map's last channel), and,
+    with_bias, db[co_off : co_off + co_real].  All maps share (N, H, W)."""
+    from ._lib import WgradJob
+    if not 1 <= len(jobs) <= WGRAD_MAX_JOBS:
+        raise ValueError("conv3x3_wgrad_multi: 1 .. %d jobs per call" % WGRAD_MAX_JOBS)
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.dim() != 4 or tuple(dw.shape[2:]) != (3, 3):
+        raise ValueError("conv3x3_wgrad_multi: dw must be a contiguous fp32 (O,I,3,3) tensor")
+    if db is not None and (db.dtype != torch.float32 or not db.is_contiguous() or db.numel() < dw.shape[0]):
+        raise ValueError("conv3x3_wgrad_multi: db must be fp32[O]")
+    arr = (WgradJob * len(jobs))()
+    shape = None
+    w_i = dw.shape[1]
+    for j, (x, xo, ci_real, ci_off, dz, zo, co_real, co_off, with_bias) in enumerate(jobs):
+        x = _req(x, torch.bfloat16, "x")
+        dz = _req(dz, torch.bfloat16, "dz")
+        if shape is None:
+            shape = tuple(x.shape[:3])
+        if tuple(x.shape[:3]) != shape or tuple(dz.shape[:3]) != shape:
+            raise ValueError("conv3x3_wgrad_multi: the maps disagree on (N,H,W)")
+        if co_off < 0 or co_off + co_real > dw.shape[0]:
+            raise ValueError("conv3x3_wgrad_multi: output-channel slice outside dw")
+        a = arr[j]
+        a.x, a.dz = x.data_ptr(), dz.data_ptr()
+        a.dw = dw.data_ptr() + co_off * w_i * 9 * 4
+        a.db = (db.data_ptr() + co_off * 4) if (with_bias and db is not None) else None
+        a.ci_real, a.ci_off, a.co_real = ci_real, ci_off, co_real
+        a.x_cstride, a.x_coff, a.dz_cstride, a.dz_coff, a.reserved = x.shape[3], xo, dz.shape[3], zo, 0
+    n, h, w = shape
+    check(lib.srhip_conv3x3_wgrad_multi(arr, len(jobs), _wgrad_workspace(jobs[0][0].device).data_ptr(), n, h, w, ci_tile, co_tile,
+                                        w_i, int(accumulate), scale, _stream()))
+
+
 def relu_mask(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy where y > 0 else 0 (bf16)."""
     dy = _req(dy, torch.bfloat16, "dy")

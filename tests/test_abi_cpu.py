@@ -113,7 +113,8 @@ def _expected_layout(fields):
 def test_every_args_struct_matches_the_header_field_for_field():
     from superresolution_amd import _lib
     for cname, cls in (("srhip_conv3x3_args", _lib.Conv3x3Args), ("srhip_conv3x3_pair_args", _lib.Conv3x3PairArgs),
-                       ("srhip_conv_gemm_args", _lib.ConvGemmArgs), ("srhip_conv1x1_chain_args", _lib.Conv1x1ChainArgs)):
+                       ("srhip_conv_gemm_args", _lib.ConvGemmArgs), ("srhip_conv1x1_chain_args", _lib.Conv1x1ChainArgs),
+                       ("srhip_wgrad_job", _lib.WgradJob)):
         fields = _header_struct_fields(cname)
         offs, size = _expected_layout(fields)
         names = [re.sub(r"\[\d+\]", "", f) for _, f in fields]
@@ -123,6 +124,7 @@ def test_every_args_struct_matches_the_header_field_for_field():
             assert getattr(cls, fld).offset == off, (cname, fld)
     assert ctypes.sizeof(_lib.Conv3x3Args) == 128 and ctypes.sizeof(_lib.Conv3x3PairArgs) == 104
     assert ctypes.sizeof(_lib.ConvGemmArgs) == 136 and ctypes.sizeof(_lib.Conv1x1ChainArgs) == 120
+    assert ctypes.sizeof(_lib.WgradJob) == 64
 
 
 def integration_snippet() -> str:

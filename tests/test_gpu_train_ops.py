@@ -101,6 +101,39 @@ def test_wgrad_concat_window_and_accumulate(F_):
     assert relerr(db.cpu().numpy(), 2 * db_ref) <= 1e-3
 
 
+@pytest.mark.parametrize("case", [((96, 64), 112, 2, 21, 40), ((160,), 256, 1, 9, 130), ((384,), 256, 2, 8, 12), ((48,), 24, 1, 5, 7)])
+def test_wgrad_of_a_wide_layer_in_batched_jobs_vs_oracle(F_, case, monkeypatch):
+    """The channel-slice pairs of a layer with more than 64 input / output channels (core/models/model_final.py:329-379)
+    go out as jobs of one launch per tile shape; against the CPU oracle, against one launch per pair, and repeatable."""
+    from superresolution_amd import autograd_ops as A_
+    srcs_c, cout, n, h, w = case
+    cin = sum(srcs_c)
+    rng = np.random.default_rng(cin + cout)
+    x = bf16r(rng.standard_normal((n, cin, h, w)))
+    dy = bf16r(rng.standard_normal((n, cout, h, w)))
+    dw_ref, db_ref = orc.conv2d_bwd_weight(x, dy, (cout, cin, 3, 3), padding=1)
+    maps, k0 = [], 0
+    for c in srcs_c:
+        cp = F_.pad16(c)
+        m = torch.zeros(n, h, w, cp, dtype=torch.bfloat16)
+        m[..., :c] = torch.from_numpy(x[:, k0:k0 + c]).permute(0, 2, 3, 1).to(torch.bfloat16)
+        maps.append(m.cuda())
+        k0 += c
+    # only the last source may carry padding for the concatenated channel index to stay contiguous
+    dz = torch.zeros(n, h, w, F_.pad16(cout), dtype=torch.bfloat16)
+    dz[..., :cout] = torch.from_numpy(dy).permute(0, 2, 3, 1).to(torch.bfloat16)
+    dz = dz.cuda()
+    wt = torch.zeros(cout, cin, 3, 3, device="cuda")
+    dw, db = A_._auto_wgrad(tuple(maps), dz, wt)
+    dw2, db2 = A_._auto_wgrad(tuple(maps), dz, wt)
+    monkeypatch.setenv("SRHIP_NO_WGRAD_MULTI", "1")
+    dw1, db1 = A_._auto_wgrad(tuple(maps), dz, wt)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert relerr(dw.cpu().numpy(), dw_ref) <= 1e-3 and relerr(db.cpu().numpy(), db_ref) <= 1e-3
+    assert relerr(dw.cpu().numpy(), dw1.cpu().numpy()) <= 1e-5 and relerr(db.cpu().numpy(), db1.cpu().numpy()) <= 1e-5
+
+
 def test_wgrad_is_deterministic(F_):
     rng = np.random.default_rng(6)
     x = bf16r(rng.standard_normal((2, 64, 150, 260)))
