@@ -255,7 +255,7 @@ class _ConvAuto(Function):
         dw, db = _auto_wgrad(srcs, dzs, w)
         dsrcs = [None] * len(srcs)
         if any(ctx.needs_input_grad[5:]):
-            dsrcs = _split_sources(_auto_dgrad(dzs, w), srcs, w.shape[1], ctx.needs_input_grad[5:])
+            dsrcs = _auto_dgrad_sources(dzs, w, srcs, ctx.needs_input_grad[5:])
         return (dw, db, None, None, None) + tuple(dsrcs)
 
 
@@ -265,8 +265,9 @@ def _auto_wgrad(srcs, dzs: Tensor, w: Tensor):
     the 3x3 result (a GEMM over a million pixels with a 160 x 160 output is a shape the GEMM library serves three times
     slower than that).  The kernel reads the channel windows in place: no slice of x or dz is copied out."""
     cout, cin, k, _ = w.shape
-    dw3 = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
-    db = torch.zeros((cout,), dtype=torch.float32, device=w.device)
+    # (every entry is written: the slice pairs tile the whole weight, the first input slice's jobs the whole bias)
+    dw3 = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=w.device)
     dz_slices = [(o, min(64, cout - o)) for o in range(0, cout, 64)]
     # all slice pairs of one tile shape go out together (one gradient launch + one reduction per group of <= 32 pairs
     # instead of one each per pair: on the 1/4 and 1/8 resolution maps a pair is a few microseconds of matrix work)
@@ -298,6 +299,24 @@ def _auto_dgrad(dzs: Tensor, w: Tensor, mask: Tensor = None) -> Tensor:
     if mask is None:
         return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2)        # (N,h,w,pad16(cin))
     return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2, res=mask, res_mode=F_.RES_MASK)
+
+
+def _auto_dgrad_sources(dzs: Tensor, w: Tensor, srcs, needs):
+    """Data gradients of a layer's sources.  A concatenated input gets one launch per source on that source's rows of the
+    transposed weights, each writing the source's gradient map directly (same values as one launch over all input
+    channels cut apart afterwards, without the zero fill and the strided copy per source)."""
+    cin, k = w.shape[1], w.shape[-1]
+    widths = [t.shape[-1] for t in srcs]
+    real = [max(0, min(c, cin - sum(widths[:i]))) for i, c in enumerate(widths)]
+    if len(srcs) == 1 or any(F_.pad16(r) != c for r, c in zip(real, widths)):
+        return _split_sources(_auto_dgrad(dzs, w), srcs, cin, needs)
+    wt = w.transpose(0, 1).flip(2, 3).contiguous() if k == 3 else w.transpose(0, 1).contiguous()
+    out, k0 = [None] * len(srcs), 0
+    for i, r in enumerate(real):
+        if needs[i]:
+            out[i] = F_.conv2d_auto(dzs, wt[k0:k0 + r], None, stride=1, padding=k // 2)
+        k0 += widths[i]
+    return out
 
 
 def _split_sources(dx: Tensor, srcs, cin: int, needs):
@@ -358,7 +377,7 @@ class _ConvReluChain(Function):
                 if dz.shape[-1] != ys[i - 1].shape[-1]:
                     dz = _split_sources(dz, (ys[i - 1],), w.shape[1], (True,))[0]
             elif any(ctx.needs_input_grad[2:2 + nsrc]):
-                dsrcs = _split_sources(_auto_dgrad(dzs, w), srcs, w.shape[1], ctx.needs_input_grad[2:2 + nsrc])
+                dsrcs = _auto_dgrad_sources(dzs, w, srcs, ctx.needs_input_grad[2:2 + nsrc])
         return (None, None) + tuple(dsrcs) + tuple(grads)
 
 
