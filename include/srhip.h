@@ -499,6 +499,16 @@ SRHIP_API int srhip_attention_fuse_bf16(const void* cur, const void* fmap, const
                                         const void* g_self, const void* f_cross, int gate_stride, void* dst, size_t pixels, int c,
                                         void* stream);
 
+/* Backward of that sum (autograd of core/models/model_final.py:422 under loss.backward(), core/trainer.py:160) from
+ * d = the gradient of dst (which is also the gradient of cur): dfmap = sigmoid(f_self * g_cross) * d, dgrad likewise, and
+ * the four gate gradients (channel sums of d * fmap / d * grad times the sigmoid's derivative times the partner gate).
+ * Each gate gradient is written as rows of dgate_stride channels per pixel, channel 0 the value and the rest zero: the
+ * gradient of the whole padded map whose channel 0 the gate is.  c in {8, 16, 32, 64}. */
+SRHIP_API int srhip_attention_fuse_bwd_bf16(const void* d, const void* fmap, const void* grad, const void* f_self, const void* g_cross,
+                                            const void* g_self, const void* f_cross, int gate_stride, void* dfmap, void* dgrad,
+                                            void* d_f_self, void* d_g_cross, void* d_g_self, void* d_f_cross, int dgate_stride,
+                                            size_t pixels, int c, void* stream);
+
 /* Second half of nn.ConvTranspose2d(k=2, s=2) (core/models/model_final.py:198-203) written as a 1x1 convolution to
  * 4*C channels: src (N,h,w,4C) bf16 with channel (i*2+j)*C + c  ->  dst (N,2h,2w,C), dst[2y+i][2x+j][c]. */
 SRHIP_API int srhip_depth_to_space2_nhwc(const void* src, void* dst, int n, int h, int w, int c, void* stream);

@@ -147,6 +147,7 @@ _SIGNATURES = {
     "srhip_max_pool2d_bwd_nhwc": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "srhip_dilate_velocity_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "srhip_attention_fuse_bf16": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "srhip_attention_fuse_bwd_bf16": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 6 + [c_int, c_size_t, c_int, c_void_p]),
     "srhip_max_pool2d_arg_nhwc": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "srhip_max_pool2d_bwd_arg_nhwc": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "srhip_resize_bilinear_bwd_nhwc": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_void_p]),

@@ -388,6 +388,32 @@ def conv_relu_chain(x, layers) -> Tensor:
     return _ConvReluChain.apply(len(srcs), tuple((s, p) for (_, _, s, p) in layers), *srcs, *flat)
 
 
+class _AttentionFuse(Function):
+    """cur + sigmoid(f_self * g_cross) * fmap + sigmoid(g_self * f_cross) * grad (core/models/model_final.py:422) as one
+    launch forward and one backward; the gates are channel 0 of padded (N,H,W,Cg) maps and receive the gradient of the
+    whole map (zeros beside channel 0)."""
+
+    @staticmethod
+    def forward(ctx, cur, fmap, grad, f_self, g_cross, g_self, f_cross):
+        ctx.save_for_backward(fmap, grad, f_self, g_cross, g_self, f_cross)
+        return F_.attention_fuse(cur, fmap, grad, f_self[..., 0:1], g_cross[..., 0:1], g_self[..., 0:1], f_cross[..., 0:1])
+
+    @staticmethod
+    def backward(ctx, d: Tensor):
+        fmap, grad, f_self, g_cross, g_self, f_cross = ctx.saved_tensors
+        d = d.contiguous()
+        out = F_.attention_fuse_bwd(d, fmap, grad, f_self[..., 0:1], g_cross[..., 0:1], g_self[..., 0:1], f_cross[..., 0:1],
+                                    gate_channels=f_self.shape[-1])
+        return (d,) + out
+
+
+def attention_fuse(cur: Tensor, fmap: Tensor, grad: Tensor, f_self: Tensor, g_cross: Tensor, g_self: Tensor, f_cross: Tensor) -> Tensor:
+    """Differentiable functional.attention_fuse; the four gates are padded maps of one width whose channel 0 counts."""
+    if len({t.shape[-1] for t in (f_self, g_cross, g_self, f_cross)}) != 1:
+        raise ValueError("attention_fuse: the gate maps must have one channel count")
+    return _AttentionFuse.apply(cur, fmap, grad, f_self, g_cross, g_self, f_cross)
+
+
 def conv2d(x, weight: Tensor, bias: Tensor, stride: int = 1, padding: int = 1, act: int = F_.ACT_NONE) -> Tensor:
     """Differentiable functional.conv2d_auto; x is an NHWC bf16 map or a tuple of maps read as their concatenation."""
     srcs = tuple(x) if isinstance(x, (tuple, list)) else (x,)

@@ -838,6 +838,65 @@ __global__ void attention_fuse_kernel(const uint4* __restrict__ cur, const uint4
     }
 }
 
+// Backward of the gated sum above (autograd of core/models/model_final.py:422 under loss.backward(), core/trainer.py:160),
+// d = gradient of dst:  dcur = d (the caller reuses d),  dfmap = wf * d,  dgrad = wg * d,
+//   d f_self = S_f * wf (1 - wf) * g_cross,  d g_cross = S_f * wf (1 - wf) * f_self,  S_f = sum over channels of d * fmap,
+//   d g_self = S_g * wg (1 - wg) * f_cross,  d f_cross = S_g * wg (1 - wg) * g_self,  S_g = sum over channels of d * grad.
+// LPP = c / 8 lanes per pixel (1, 2, 4 or 8), each 8 channels; the channel sums cross the lanes of a pixel by shuffles.
+// A gate gradient is written as a whole row of dgate_stride channels: channel 0 the value, the others zero (the gates
+// are channel 0 of 16-channel padded maps, and the layer that produced them takes the gradient of the whole map).
+template <int LPP>
+__global__ void attention_fuse_bwd_kernel(const uint4* __restrict__ d, const uint4* __restrict__ fmap, const uint4* __restrict__ grad,
+                                          const unsigned short* __restrict__ f_self, const unsigned short* __restrict__ g_cross,
+                                          const unsigned short* __restrict__ g_self, const unsigned short* __restrict__ f_cross,
+                                          int gate_stride, uint4* __restrict__ dfmap, uint4* __restrict__ dgrad,
+                                          uint4* __restrict__ d_f_self, uint4* __restrict__ d_g_cross, uint4* __restrict__ d_g_self,
+                                          uint4* __restrict__ d_f_cross, int dgate_vecs, long long nvec)
+{
+    // the grid covers nvec rounded up to whole waves: every lane of a wave takes part in the shuffles
+    const long long nvec_up = (nvec + 63) / 64 * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec_up; i += (long long)gridDim.x * blockDim.x) {
+        const bool live = i < nvec;
+        const long long iv = live ? i : nvec - 1;
+        const long long px = iv / LPP;
+        const float fs = bf16_bits_to_f32(f_self[px * gate_stride]), gc = bf16_bits_to_f32(g_cross[px * gate_stride]);
+        const float gs = bf16_bits_to_f32(g_self[px * gate_stride]), fc = bf16_bits_to_f32(f_cross[px * gate_stride]);
+        const float wf = 1.0f / (1.0f + expf(-(fs * gc)));
+        const float wg = 1.0f / (1.0f + expf(-(gs * fc)));
+        float dv[8], fv[8], gv[8], o1[8], o2[8];
+        unpack8(d[iv], dv);
+        unpack8(fmap[iv], fv);
+        unpack8(grad[iv], gv);
+        float sf = 0.0f, sg = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o1[e] = __fmul_rn(wf, dv[e]);
+            o2[e] = __fmul_rn(wg, dv[e]);
+            sf = __builtin_fmaf(dv[e], fv[e], sf);
+            sg = __builtin_fmaf(dv[e], gv[e], sg);
+        }
+        if (live) {
+            dfmap[i] = pack8(o1);
+            dgrad[i] = pack8(o2);
+        }
+#pragma unroll
+        for (int m = 1; m < LPP; m <<= 1) {   // the lanes of a pixel are LPP consecutive lanes of one wave
+            sf += __shfl_xor(sf, m);
+            sg += __shfl_xor(sg, m);
+        }
+        if (live && (iv % LPP) == 0) {
+            const float kf = sf * wf * (1.0f - wf), kg = sg * wg * (1.0f - wg);
+            const unsigned vals[4] = {f32_to_bf16_bits(kf * gc), f32_to_bf16_bits(kf * fs), f32_to_bf16_bits(kg * fc), f32_to_bf16_bits(kg * gs)};
+            uint4* const rows[4] = {d_f_self, d_g_cross, d_g_self, d_f_cross};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rows[k][px * dgate_vecs] = make_uint4(vals[k], 0u, 0u, 0u);
+                for (int v = 1; v < dgate_vecs; ++v) rows[k][px * dgate_vecs + v] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+}
+
 // ---- backward kernels of the ESA block and of LeakyReLU (autograd of core/arch/RepRFN.py:295-308,17-33) ----
 // dst = dy * (y > 0 ? 1 : slope): backward of (Leaky)ReLU from its OUTPUT (slope > 0 keeps the sign)
 __global__ void lrelu_mask_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ y, uint4* __restrict__ dst,
@@ -2415,6 +2474,28 @@ SRHIP_API int srhip_attention_fuse_bf16(const void* cur, const void* fmap, const
                        (const unsigned short*)g_cross, (const unsigned short*)g_self, (const unsigned short*)f_cross, gate_stride,
                        (uint4*)dst, nvec, c / 8);
     return srhip_check_launch("attention_fuse_bf16");
+}
+
+SRHIP_API int srhip_attention_fuse_bwd_bf16(const void* d, const void* fmap, const void* grad, const void* f_self, const void* g_cross,
+                                            const void* g_self, const void* f_cross, int gate_stride, void* dfmap, void* dgrad,
+                                            void* d_f_self, void* d_g_cross, void* d_g_self, void* d_f_cross, int dgate_stride,
+                                            size_t pixels, int c, void* stream)
+{
+    SRHIP_REQUIRE(d && fmap && grad && f_self && g_cross && g_self && f_cross && dfmap && dgrad && d_f_self && d_g_cross && d_g_self && d_f_cross,
+                  "attention_fuse_bwd_bf16: null pointer");
+    SRHIP_REQUIRE(c == 8 || c == 16 || c == 32 || c == 64, "attention_fuse_bwd_bf16: c must be 8, 16, 32 or 64 (got %d)", c);
+    SRHIP_REQUIRE(gate_stride >= 1 && dgate_stride >= 8 && dgate_stride % 8 == 0, "attention_fuse_bwd_bf16: gate_stride >= 1, dgate_stride a multiple of 8");
+    if (pixels == 0) return SRHIP_OK;
+    const long long nvec = (long long)pixels * (c / 8);
+    const dim3 grid(grid_for((nvec + 63) / 64 * 64, srhip_num_cus())), block(kThreads);
+#define SRHIP_AFB_CASE(L) \
+    if (c == 8 * L) hipLaunchKernelGGL(attention_fuse_bwd_kernel<L>, grid, block, 0, (hipStream_t)stream, (const uint4*)d, (const uint4*)fmap, \
+        (const uint4*)grad, (const unsigned short*)f_self, (const unsigned short*)g_cross, (const unsigned short*)g_self, \
+        (const unsigned short*)f_cross, gate_stride, (uint4*)dfmap, (uint4*)dgrad, (uint4*)d_f_self, (uint4*)d_g_cross, (uint4*)d_g_self, \
+        (uint4*)d_f_cross, dgate_stride / 8, nvec);
+    SRHIP_AFB_CASE(1) SRHIP_AFB_CASE(2) SRHIP_AFB_CASE(4) SRHIP_AFB_CASE(8)
+#undef SRHIP_AFB_CASE
+    return srhip_check_launch("attention_fuse_bwd_bf16");
 }
 
 SRHIP_API int srhip_lrelu_mask_bf16(const void* dy, const void* y, void* dst, size_t count, float slope, void* stream)

@@ -1147,6 +1147,31 @@ def attention_fuse(cur: torch.Tensor, fmap: torch.Tensor, grad: torch.Tensor, f_
     return out
 
 
+def attention_fuse_bwd(d: torch.Tensor, fmap: torch.Tensor, grad: torch.Tensor, f_self: torch.Tensor, g_cross: torch.Tensor,
+                       g_self: torch.Tensor, f_cross: torch.Tensor, gate_channels: int = 16):
+    """Backward of attention_fuse from d = the gradient of its result (also the gradient of ``cur``): returns (dfmap, dgrad,
+    d_f_self, d_g_cross, d_g_self, d_f_cross); the gate gradients are (N,H,W,gate_channels) maps with the value in channel
+    0 and zeros elsewhere (the gradient of the padded map whose channel 0 the gate is)."""
+    d, fmap, grad = _req(d, torch.bfloat16, "d"), _req(fmap, torch.bfloat16, "fmap"), _req(grad, torch.bfloat16, "grad")
+    if fmap.shape != d.shape or grad.shape != d.shape:
+        raise ValueError("attention_fuse_bwd: d, fmap and grad must have one shape")
+    n, h, w, c = d.shape
+    gates = (f_self, g_cross, g_self, f_cross)
+    gs = gates[0].stride(2)
+    for t in gates:
+        if t.dtype != torch.bfloat16 or not t.is_cuda or tuple(t.shape) != (n, h, w, 1) or t.stride() != (h * w * gs, w * gs, gs, 1):
+            raise ValueError("attention_fuse_bwd: every gate must be a (N,H,W,1) bf16 view with pixel stride %d" % gs)
+    if gate_channels < 8 or gate_channels % 8:
+        raise ValueError("attention_fuse_bwd: gate_channels must be a multiple of 8")
+    dfmap, dgrad = torch.empty_like(d), torch.empty_like(d)
+    dg = [torch.empty((n, h, w, gate_channels), dtype=torch.bfloat16, device=d.device) for _ in range(4)]
+    check(lib.srhip_attention_fuse_bwd_bf16(d.data_ptr(), fmap.data_ptr(), grad.data_ptr(), f_self.data_ptr(), g_cross.data_ptr(),
+                                            g_self.data_ptr(), f_cross.data_ptr(), gs, dfmap.data_ptr(), dgrad.data_ptr(),
+                                            dg[0].data_ptr(), dg[1].data_ptr(), dg[2].data_ptr(), dg[3].data_ptr(), gate_channels,
+                                            n * h * w, c, _stream()))
+    return (dfmap, dgrad) + tuple(dg)
+
+
 def max_pool2d_arg_nhwc(x: torch.Tensor, k: int, s: int):
     """max_pool2d_nhwc that also returns the window position of every maximum ((N,ho,wo,C) uint8), for the backward."""
     x = _req(x, torch.bfloat16, "x")

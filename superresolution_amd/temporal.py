@@ -324,7 +324,9 @@ class Attention(nn.Module):
         self.w_cross = ConvActivation(cin, 1)
 
     def run(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
-        if torch.is_grad_enabled() or _TRACE is not None:
+        if torch.is_grad_enabled():   # training: the whole padded gate maps (channel 0 counts; the gated sum's backward
+            return self.conv.run(x), self.w_self.run(x), self.w_cross.run(x)   # returns the gradient of the whole map)
+        if _TRACE is not None:
             return self.conv.run(x), self.w_self.run(x)[..., 0:1], self.w_cross.run(x)[..., 0:1]
         # inference: the two one-channel layers read the same map -> one launch with both kernels (channels 0 and 1)
         w2, b2 = self._gate_kernels()
@@ -368,10 +370,14 @@ class MainNetwork(nn.Module):
         fmap, f_self, f_cross = self.attn_fmap.run(fmap_current)
         _rec("main_network.grad_map", folded, 6 * self.sr_scale ** 2)
         if torch.is_grad_enabled():
-            # model_final.py:422 (gates broadcast over the channels), formed in fp32 and rounded once like the inference
-            # kernel's; the gradients re-enter the bf16 maps through the casts
-            cur = (fmap_current.float() + torch.sigmoid(f_self.float() * g_cross.float()) * fmap.float()
-                   + torch.sigmoid(g_self.float() * f_cross.float()) * grad.float()).to(torch.bfloat16)
+            # model_final.py:422 (gates broadcast over the channels): one launch, formed in fp32 and rounded once, and one
+            # launch for its backward (SRHIP_NO_FUSED_GATE=1: the same sum in torch operators)
+            if os.environ.get("SRHIP_NO_FUSED_GATE", "0") == "1":
+                f_self, g_cross, g_self, f_cross = (t[..., 0:1] for t in (f_self, g_cross, g_self, f_cross))
+                cur = (fmap_current.float() + torch.sigmoid(f_self.float() * g_cross.float()) * fmap.float()
+                       + torch.sigmoid(g_self.float() * f_cross.float()) * grad.float()).to(torch.bfloat16)
+            else:
+                cur = A_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)
         else:                         # ... as one kernel
             cur = F_.attention_fuse(fmap_current, fmap, grad, f_self, g_cross, g_self, f_cross)
         _rec("main_network.cur", cur, cur.shape[-1])

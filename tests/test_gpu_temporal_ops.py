@@ -342,3 +342,33 @@ def test_conv1x1_chain_equals_the_three_layers(case):
         assert np.abs(got.float().permute(0, 3, 1, 2).cpu().numpy() - o).max() <= 2e-2 * max(1.0, float(np.abs(o).max()))
     # an unsupported chain is refused, not mis-run
     assert not F_.conv1x1_chain_supported([64, 64, 64, 64], False)
+
+
+@pytest.mark.parametrize("case", [(2, 9, 21, 64, 16), (1, 5, 7, 32, 16), (1, 3, 50, 16, 8), (1, 4, 4, 8, 16)])
+def test_attention_fuse_backward_vs_torch_autograd(case):
+    """Backward of the gated sum (core/models/model_final.py:422 under autograd): against torch's autograd of the same
+    formula in fp32 on the same bf16 operands; results are bf16, so the bar is one bf16 rounding (2^-8 relative) plus the
+    fp32 summation order of the channel sums."""
+    from superresolution_amd import autograd_ops as A_
+    n, h, w, c, cg = case
+    g = torch.Generator().manual_seed(c + h)
+    mk = lambda *s: ((torch.rand(*s, generator=g) - 0.5) * 2).to(torch.bfloat16).cuda()
+    cur, fmap, grad = mk(n, h, w, c), mk(n, h, w, c), mk(n, h, w, c)
+    gates = [mk(n, h, w, cg) for _ in range(4)]
+    d = mk(n, h, w, c)
+    ins = [t.clone().requires_grad_(True) for t in (cur, fmap, grad, *gates)]
+    out = A_.attention_fuse(*ins)
+    out.backward(d)
+    ref_in = [t.float().clone().requires_grad_(True) for t in (cur, fmap, grad, *gates)]
+    rc, rf, rg, fs, gc, gs, fc = ref_in
+    ref = rc + torch.sigmoid(fs[..., 0:1] * gc[..., 0:1]) * rf + torch.sigmoid(gs[..., 0:1] * fc[..., 0:1]) * rg
+    ref.backward(d.float())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref.to(torch.bfloat16)) or float((out.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    for got, want in zip(ins, ref_in):
+        a, b = got.grad.float(), want.grad
+        assert a.shape == b.shape
+        tol = 2.0 ** -8 * b.abs() + 1e-5 * float(b.abs().max()) + 1e-30
+        assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() - tol).max())
+    for got in ins[3:]:
+        assert float(got.grad[..., 1:].abs().max()) == 0.0   # only channel 0 of a gate map carries gradient
