@@ -368,6 +368,18 @@ SRHIP_API int srhip_l1_ssim_loss(const float* sr, const float* target, float* ds
                                  void* workspace, int planes, int h, int w, float lambda_l1,
                                  float lambda_ssim, float clip_min, float clip_max, void* stream);
 
+/* Pixel-weighted L1 of the temporal variant, forward AND backward in one call: the network's second output is a per-pixel
+ * loss weight at the input resolution (enhance_weight, core/models/model_final.py:499-505); broadcast over the channels
+ * and, nearest, over the (h / wh) x (w / ww) output pixels each of its pixels covers,
+ *   loss = mean over (n, c, h, w) of (1 + weight[n, 0, y / (h/wh), x / (w/ww)]) * |sr - target|,
+ * out1 (device) = loss, dsr = dloss/dsr ((1 + weight) * sign(sr - target) / count; 0 where sr == target).
+ * sr, target, dsr: (n, c, h, w) fp32, 16-byte aligned, w a multiple of 4; weight: (n, 1, wh, ww) fp32 (no gradient: the
+ * weight is computed from the inputs alone).  workspace: srhip_weighted_l1_workspace_bytes() bytes, caller-owned.
+ * Deterministic (fixed-order two-stage sum). */
+SRHIP_API size_t srhip_weighted_l1_workspace_bytes(void);
+SRHIP_API int srhip_weighted_l1_loss(const float* sr, const float* target, const float* weight, float* dsr, float* out1,
+                                     void* workspace, int n, int c, int h, int w, int wh, int ww, void* stream);
+
 /* Motion-vector backward warp, core/tools/math.py:10-17 (grid (x,y)-last as the
  * function evidently intends): frame (N,C,h,w), motion (N,2,h,w) in pixels,
  * zero padding.  fp32 NCHW in/out. */

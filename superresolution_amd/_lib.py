@@ -124,6 +124,8 @@ _SIGNATURES = {
     "srhip_esa_tail_bf16": (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
     "srhip_l1_ssim_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_l1_ssim_loss": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 4 + [c_void_p]),
+    "srhip_weighted_l1_workspace_bytes": (c_size_t, []),
+    "srhip_weighted_l1_loss": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "srhip_backward_warp_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_warp_concat_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "srhip_backward_warp_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

@@ -494,9 +494,82 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __rest
     }
 }
 
+// ---- pixel-weighted L1: loss = mean((1 + weight at the pixel's low-resolution position) * |sr - target|) ----
+// The temporal network's second output is a per-pixel loss weight at the input resolution
+// (core/models/model_final.py:499-505: enhance_weight); the loss that uses it broadcasts it over the channels and the
+// scale x scale pixels it covers (nearest).  One pass reads sr and target once and writes dsr = d loss / d sr and one
+// partial sum per work-group; a second launch adds the partial sums in a fixed order (in double).
+constexpr int WL1_THREADS = 256;
+__global__ __launch_bounds__(WL1_THREADS) void weighted_l1_kernel(const float4* __restrict__ sr, const float4* __restrict__ y,
+                                                                  const float* __restrict__ wt, float4* __restrict__ dsr,
+                                                                  float* __restrict__ partial, int c, int h, int w4, int wh, int ww,
+                                                                  int ry, int rx, long long nvec, float inv_n)
+{
+    __shared__ float red[WL1_THREADS / 64];
+    float acc = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(i % w4);
+        long long t = i / w4;
+        const int yy = (int)(t % h);
+        t /= h;                                   // plane = image * c + channel
+        const long long img = t / c;
+        const float* wrow = wt + (img * wh + yy / ry) * ww;
+        const float4 a = sr[i], b = y[i];
+        const float dv[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float k = 1.0f + wrow[(4 * x4 + e) / rx];
+            acc += k * fabsf(dv[e]);
+            o[e] = dv[e] > 0.0f ? k * inv_n : (dv[e] < 0.0f ? -k * inv_n : 0.0f);
+        }
+        dsr[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void weighted_l1_sum_kernel(const float* __restrict__ partial, int nparts, double inv_n, float* __restrict__ out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
+
 }  // namespace
 
 extern "C" {
+
+SRHIP_API size_t srhip_weighted_l1_workspace_bytes(void) { return (size_t)srhip_num_cus() * 8 * sizeof(float); }
+
+SRHIP_API int srhip_weighted_l1_loss(const float* sr, const float* target, const float* weight, float* dsr, float* out1,
+                                     void* workspace, int n, int c, int h, int w, int wh, int ww, void* stream)
+{
+    SRHIP_REQUIRE(sr && target && weight && dsr && out1 && workspace, "weighted_l1_loss: null pointer");
+    SRHIP_REQUIRE(n >= 1 && c >= 1 && h >= 1 && w >= 1 && wh >= 1 && ww >= 1, "weighted_l1_loss: empty tensor");
+    SRHIP_REQUIRE(h % wh == 0 && w % ww == 0, "weighted_l1_loss: the weight map (%d x %d) must divide the image (%d x %d)", wh, ww, h, w);
+    SRHIP_REQUIRE(w % 4 == 0, "weighted_l1_loss: the image width must be a multiple of 4");
+    SRHIP_REQUIRE(((size_t)sr | (size_t)target | (size_t)dsr) % 16 == 0, "weighted_l1_loss: sr, target and dsr must be 16-byte aligned");
+    const long long count = (long long)n * c * h * w;
+    const long long nvec = count / 4;
+    const int blocks = (int)(nvec < (long long)srhip_num_cus() * 8 * WL1_THREADS ? (nvec + WL1_THREADS - 1) / WL1_THREADS : (long long)srhip_num_cus() * 8);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(weighted_l1_kernel, dim3(blocks), dim3(WL1_THREADS), 0, s, (const float4*)sr, (const float4*)target, weight,
+                       (float4*)dsr, (float*)workspace, c, h, w / 4, wh, ww, h / wh, w / ww, nvec, (float)(1.0 / (double)count));
+    int rc = srhip_check_launch("weighted_l1_kernel");
+    if (rc != SRHIP_OK) return rc;
+    hipLaunchKernelGGL(weighted_l1_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, blocks, 1.0 / (double)count, out1);
+    return srhip_check_launch("weighted_l1_sum_kernel");
+}
 
 SRHIP_API size_t srhip_l1_ssim_workspace_bytes(int planes, int h, int w)
 {

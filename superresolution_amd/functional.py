@@ -740,6 +740,25 @@ def l1_ssim_loss(sr: torch.Tensor, target: torch.Tensor, lambda_l1: float, lambd
     return out3, dsr
 
 
+def weighted_l1_loss(sr: torch.Tensor, target: torch.Tensor, weight: torch.Tensor):
+    """mean((1 + weight, nearest-upsampled and broadcast over the channels) * |sr - target|) and its gradient:
+    returns (loss (1,) device tensor, dsr).  sr / target (N,C,H,W) fp32, weight (N,1,h,w) fp32 with h | H, w | W."""
+    sr = _req(sr, torch.float32, "sr")
+    target = _req(target, torch.float32, "target")
+    weight = _req(weight, torch.float32, "weight")
+    if sr.shape != target.shape or sr.dim() != 4:
+        raise ValueError("weighted_l1_loss: sr and target must be equal-shape (N,C,H,W) tensors")
+    n, c, h, w = sr.shape
+    if weight.dim() != 4 or weight.shape[0] != n or weight.shape[1] != 1:
+        raise ValueError("weighted_l1_loss: weight must be (N,1,h,w)")
+    ws = torch.empty((lib.srhip_weighted_l1_workspace_bytes(),), dtype=torch.uint8, device=sr.device)
+    dsr = torch.empty_like(sr)
+    out = torch.empty((1,), dtype=torch.float32, device=sr.device)
+    check(lib.srhip_weighted_l1_loss(sr.data_ptr(), target.data_ptr(), weight.data_ptr(), dsr.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                     n, c, h, w, weight.shape[2], weight.shape[3], _stream()))
+    return out, dsr
+
+
 def conv2d_direct(src: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], cin: int, stride=1, padding=0,
                   res: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.0, alpha: float = 1.0,
                   cout_stride: Optional[int] = None) -> torch.Tensor:

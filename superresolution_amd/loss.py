@@ -46,3 +46,24 @@ class FusedLossGroup(nn.Module):
             v = parts.tolist()
             loss_dict = {"l1": v[0], "ssim": v[1], "total": v[2]}
         return loss, loss_dict
+
+
+class _WeightedL1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sr: Tensor, target: Tensor, weight: Tensor):
+        from . import functional as F_
+        out, dsr = F_.weighted_l1_loss(sr, target, weight)
+        ctx.dsr = dsr
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        dsr, ctx.dsr = ctx.dsr, None
+        return dsr.mul_(g), None, None
+
+
+def enhance_weighted_l1(sr: Tensor, target: Tensor, enhance_weight: Tensor) -> Tensor:
+    """``((1 + nearest_upsample(enhance_weight)) * (sr - target).abs()).mean()`` in one HIP call, value and gradient: the
+    pixel-wise loss weight is the temporal network's second output (core/models/model_final.py:499-505), (N,1,h,w) at the
+    input resolution; it carries no gradient (it is computed from the inputs alone)."""
+    return _WeightedL1Fn.apply(sr, target, enhance_weight.detach())

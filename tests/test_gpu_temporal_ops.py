@@ -372,3 +372,33 @@ def test_attention_fuse_backward_vs_torch_autograd(case):
         assert bool(((a - b).abs() <= tol).all()), float(((a - b).abs() - tol).max())
     for got in ins[3:]:
         assert float(got.grad[..., 1:].abs().max()) == 0.0   # only channel 0 of a gate map carries gradient
+
+
+@pytest.mark.parametrize("case", [(2, 3, 64, 96, 4), (1, 3, 30, 52, 2), (3, 1, 8, 8, 1), (1, 3, 256, 1024, 4)])
+def test_enhance_weighted_l1_vs_torch(case):
+    """loss = mean((1 + nearest-upsampled weight) * |sr - target|) (the temporal variant's pixel-wise loss weight,
+    core/models/model_final.py:499-505) and its gradient, against the same formula in torch operators under autograd:
+    value to 1e-6 relative (fp32 sums in a different order), gradient to one fp32 rounding; zero gradient where sr equals
+    the target; repeatable bit for bit."""
+    from superresolution_amd.loss import enhance_weighted_l1
+    n, c, h, w, r = case
+    g = torch.Generator().manual_seed(h + w)
+    sr = torch.rand(n, c, h, w, generator=g).cuda()
+    target = torch.rand(n, c, h, w, generator=g).cuda()
+    target[:, :, ::3, ::5] = sr[:, :, ::3, ::5]
+    ew = torch.rand(n, 1, h // r, w // r, generator=g).cuda()
+    a = sr.clone().requires_grad_(True)
+    loss = enhance_weighted_l1(a, target, ew)
+    (loss * 3.0).backward()
+    b = sr.clone().requires_grad_(True)
+    wmap = torch.nn.functional.interpolate(ew, size=(h, w), mode="nearest")
+    ref = ((1.0 + wmap) * (b - target).abs()).mean()
+    (ref * 3.0).backward()
+    a2 = sr.clone().requires_grad_(True)
+    loss2 = enhance_weighted_l1(a2, target, ew)
+    (loss2 * 3.0).backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * abs(float(ref.detach()))
+    assert float((a.grad - b.grad).abs().max()) <= 2e-7 * float(b.grad.abs().max())
+    assert float(a.grad[:, :, ::3, ::5].abs().max()) == 0.0
+    assert torch.equal(loss, loss2) and torch.equal(a.grad, a2.grad)
