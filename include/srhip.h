@@ -201,6 +201,14 @@ typedef struct {
 SRHIP_API size_t srhip_conv_gemm_packed_bytes(int cin_padded, int cout, int ksize);
 SRHIP_API int srhip_conv_gemm_pack_weights(const float* weight, void* packed, int cout, int cin, int ksize, int cin_padded,
                                            void* stream);
+/* The same for the layer's data gradient (autograd of nn.Conv2d under loss.backward(), core/trainer.py:160): packs, from
+ * the stored fp32 (w_o, w_i, k, k) weight, the layer whose output channel co is the stored input channel row0 + co
+ * (co < rows: the channel range of one source of a concatenated input), whose input channels are the stored output
+ * channels (padded to cin_padded) and whose kernel is the stored one flipped in both directions -- what
+ * weight.transpose(0, 1).flip(2, 3)[row0 : row0 + rows] would hold, without materialising it.
+ * packed: srhip_conv_gemm_packed_bytes(cin_padded, rows, ksize) bytes. */
+SRHIP_API int srhip_conv_gemm_pack_weights_transposed(const float* weight, void* packed, int w_o, int w_i, int ksize, int row0,
+                                                      int rows, int cin_padded, void* stream);
 SRHIP_API int srhip_conv_gemm_fwd(const srhip_conv_gemm_args* args, void* stream);
 
 /* A chain of three 1x1 convolutions, each + bias + activation, as ONE pass: the maps between the layers never leave the

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "srhip_conv3x3_pair_bits_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_conv_gemm_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srhip_conv_gemm_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "srhip_conv_gemm_pack_weights_transposed": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_conv_gemm_fwd": (c_int, [ctypes.POINTER(ConvGemmArgs), c_void_p]),
     "srhip_conv1x1_chain_fwd": (c_int, [ctypes.POINTER(Conv1x1ChainArgs), c_void_p]),
     "srhip_conv1x1_chain_supported": (c_int, [ctypes.POINTER(c_int), c_int, c_int]),

@@ -291,14 +291,25 @@ def _auto_wgrad(srcs, dzs: Tensor, w: Tensor):
     return (dw3 if k == 3 else dw3[:, :, 1:2, 1:2].contiguous()), db
 
 
-def _auto_dgrad(dzs: Tensor, w: Tensor, mask: Tensor = None) -> Tensor:
-    """Data gradient w.r.t. the concatenated input: the same operator on transposed (3x3: flipped) weights; ``mask`` (the
-    ReLU output of the layer in front) is applied by the launch's epilogue."""
-    k = w.shape[-1]
-    wt = w.transpose(0, 1).flip(2, 3).contiguous() if k == 3 else w.transpose(0, 1).contiguous()
+def _dgrad_rows(dzs: Tensor, w: Tensor, row0: int, rows: int, mask: Tensor = None) -> Tensor:
+    """Data gradient w.r.t. input channels [row0, row0 + rows) of a layer: the same operator on transposed (3x3: flipped)
+    weights; ``mask`` (the ReLU output of the layer in front) is applied by the launch's epilogue.  On the implicit-GEMM
+    kernel the transposed weights are packed straight from the stored ones; a layer that is one launch of the
+    register-resident kernel (<= 64 channels both ways) materialises them for that kernel's packer."""
+    k, cpad = w.shape[-1], dzs.shape[-1]
+    if F_.use_conv_gemm and (cpad > 64 or rows > 64) and cpad % 16 == 0 and os.environ.get("SRHIP_NO_PACK_T", "0") != "1":
+        wp = F_.conv_gemm_pack_weights_transposed(w, row0, rows, cpad)
+        return F_.conv_gemm(dzs, wp, None, rows, k, stride=1, padding=k // 2, res=mask,
+                            res_mode=F_.RES_MASK if mask is not None else F_.RES_ADD)
+    wt = (w.transpose(0, 1).flip(2, 3) if k == 3 else w.transpose(0, 1))[row0:row0 + rows].contiguous()
     if mask is None:
-        return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2)        # (N,h,w,pad16(cin))
+        return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2)        # (N,h,w,pad16(rows))
     return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2, res=mask, res_mode=F_.RES_MASK)
+
+
+def _auto_dgrad(dzs: Tensor, w: Tensor, mask: Tensor = None) -> Tensor:
+    """Data gradient w.r.t. the concatenated input."""
+    return _dgrad_rows(dzs, w, 0, w.shape[1], mask)
 
 
 def _auto_dgrad_sources(dzs: Tensor, w: Tensor, srcs, needs):
@@ -310,11 +321,10 @@ def _auto_dgrad_sources(dzs: Tensor, w: Tensor, srcs, needs):
     real = [max(0, min(c, cin - sum(widths[:i]))) for i, c in enumerate(widths)]
     if len(srcs) == 1 or any(F_.pad16(r) != c for r, c in zip(real, widths)):
         return _split_sources(_auto_dgrad(dzs, w), srcs, cin, needs)
-    wt = w.transpose(0, 1).flip(2, 3).contiguous() if k == 3 else w.transpose(0, 1).contiguous()
     out, k0 = [None] * len(srcs), 0
     for i, r in enumerate(real):
         if needs[i]:
-            out[i] = F_.conv2d_auto(dzs, wt[k0:k0 + r], None, stride=1, padding=k // 2)
+            out[i] = _dgrad_rows(dzs, w, k0, r)
         k0 += widths[i]
     return out
 

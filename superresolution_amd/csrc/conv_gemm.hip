@@ -448,9 +448,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gemm_kernel(const GemmParams
     }
 }
 
-// fp32 OIHW (or OI11) master weights -> bf16 MFMA fragment order [tap][16-channel chunk][32-channel tile][lane][8]
+// fp32 OIHW (or OI11) master weights -> bf16 MFMA fragment order [tap][16-channel chunk][32-channel tile][lane][8].
+// transposed: the packed layer is the data-gradient layer of the stored one -- its output channel co is the stored
+// weight's input channel row0 + co, its input channel ci the stored output channel, its kernel the stored one flipped
+// in both directions (w_i = input channels of the stored weight).
 __global__ void gemm_pack_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout, int cin,
-                                         int ks, int kc_total, int ct_total, int total)
+                                         int ks, int kc_total, int ct_total, int total, int transposed, int row0, int w_i)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -464,7 +467,9 @@ __global__ void gemm_pack_weights_kernel(const float* __restrict__ w, unsigned s
     const int co = ct * 32 + (lane & 31);
     const int ci = kc * 16 + 8 * (lane >> 5) + j;
     float v = 0.0f;
-    if (co < cout && ci < cin) v = w[(((long long)co * cin + ci) * ks + ky) * ks + kx];
+    if (co < cout && ci < cin)
+        v = transposed ? w[(((long long)ci * w_i + row0 + co) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)]
+                       : w[(((long long)co * cin + ci) * ks + ky) * ks + kx];
     out[idx] = f32_to_bf16_bits(v);
 }
 
@@ -549,7 +554,22 @@ SRHIP_API int srhip_conv_gemm_pack_weights(const float* weight, void* packed, in
     const long long total = (long long)ksize * ksize * kc_total * ct_total * 512;
     SRHIP_REQUIRE(total < (1ll << 31), "conv_gemm_pack_weights: weight too large");
     hipLaunchKernelGGL(gemm_pack_weights_kernel, dim3(srhip_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                       (unsigned short*)packed, cout, cin, ksize, kc_total, ct_total, (int)total);
+                       (unsigned short*)packed, cout, cin, ksize, kc_total, ct_total, (int)total, 0, 0, 0);
+    return srhip_check_launch("gemm_pack_weights_kernel");
+}
+
+SRHIP_API int srhip_conv_gemm_pack_weights_transposed(const float* weight, void* packed, int w_o, int w_i, int ksize, int row0,
+                                                      int rows, int cin_padded, void* stream)
+{
+    SRHIP_REQUIRE(weight && packed, "conv_gemm_pack_weights_transposed: null pointer");
+    SRHIP_REQUIRE(w_o >= 1 && w_i >= 1 && (ksize == 1 || ksize == 3), "conv_gemm_pack_weights_transposed: bad shape");
+    SRHIP_REQUIRE(row0 >= 0 && rows >= 1 && row0 + rows <= w_i, "conv_gemm_pack_weights_transposed: rows [%d,%d) outside the weight's %d input channels", row0, row0 + rows, w_i);
+    SRHIP_REQUIRE(cin_padded >= w_o && cin_padded % 16 == 0, "conv_gemm_pack_weights_transposed: cin_padded must be a multiple of 16 and >= the weight's output channels");
+    const int kc_total = cin_padded / 16, ct_total = (rows + 31) / 32;
+    const long long total = (long long)ksize * ksize * kc_total * ct_total * 512;
+    SRHIP_REQUIRE(total < (1ll << 31), "conv_gemm_pack_weights_transposed: weight too large");
+    hipLaunchKernelGGL(gemm_pack_weights_kernel, dim3(srhip_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       (unsigned short*)packed, rows, w_o, ksize, kc_total, ct_total, (int)total, 1, row0, w_i);
     return srhip_check_launch("gemm_pack_weights_kernel");
 }
 

@@ -589,6 +589,23 @@ def conv_gemm_pack_weights(weight: torch.Tensor, cin_padded: int) -> torch.Tenso
     return packed
 
 
+def conv_gemm_pack_weights_transposed(weight: torch.Tensor, row0: int, rows: int, cin_padded: int) -> torch.Tensor:
+    """Packed fragments of the data-gradient layer of a stored fp32 (O, I, k, k) weight: what
+    ``conv_gemm_pack_weights(weight.transpose(0, 1).flip(2, 3)[row0:row0 + rows], cin_padded)`` gives, in one kernel."""
+    weight = _req(weight, torch.float32, "weight")
+    w_o, w_i, kh, kw = weight.shape
+    if kh != kw or kh not in (1, 3):
+        raise ValueError("conv_gemm_pack_weights_transposed: kernel must be 1x1 or 3x3")
+    if row0 < 0 or rows < 1 or row0 + rows > w_i:
+        raise ValueError("conv_gemm_pack_weights_transposed: rows outside the weight's input channels")
+    nbytes = lib.srhip_conv_gemm_packed_bytes(cin_padded, rows, kh)
+    if nbytes == 0 or cin_padded < w_o:
+        raise ValueError("conv_gemm_pack_weights_transposed: cin_padded must be a multiple of 16 and >= the weight's output channels")
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+    check(lib.srhip_conv_gemm_pack_weights_transposed(weight.data_ptr(), packed.data_ptr(), w_o, w_i, kh, row0, rows, cin_padded, _stream()))
+    return packed
+
+
 def conv_gemm(srcs, wpack: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ksize: int, stride: int = 1, padding: int = 0,
               act: int = ACT_NONE, slope: float = 0.0, alpha: float = 1.0, res: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None, res_mode: int = RES_ADD) -> torch.Tensor:
