@@ -1908,6 +1908,122 @@ __global__ void layernorm_cf_bwd_dx_kernel(const float* __restrict__ x, const fl
     }
 }
 
+// Register-resident forms for c <= 64 (the path's LayerNorms have 60-64 channels): a thread keeps its pixel's x (and dy)
+// in registers, so every tensor crosses HBM once (the loops above re-read x four times and dy twice through the caches, and
+// the parameter pass reads both again).  Same operation order per pixel as the loops above: bit-equal y and dx.
+constexpr int kLnRegC = 64;
+__global__ __launch_bounds__(256) void layernorm_cf_reg_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int n, int c,
+                                                               long long hw, float eps)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n * hw) return;
+    const long long img = i / hw, pix = i - img * hw;
+    const float* xp = x + img * c * hw + pix;
+    float* yp = y + img * c * hw + pix;
+    float xv[kLnRegC];
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) xv[k] = k < c ? xp[(long long)k * hw] : 0.0f;
+    float u = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) if (k < c) u += xv[k];
+    u = u / (float)c;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) if (k < c) { const float d = xv[k] - u; s += d * d; }
+    s = s / (float)c;
+    const float den = sqrtf(s + eps);
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) if (k < c) yp[(long long)k * hw] = weight[k] * ((xv[k] - u) / den) + bias[k];
+}
+
+// Backward: dx as above, and the parameter sums of the block's 256 pixels.  A wave adds its 64 lanes' 128 values
+// (dy * xhat and dy per channel, interleaved) by a halving butterfly: at distance m a lane hands the half of its values
+// that its partner keeps across and adds what it receives to the half it keeps (126 exchanges instead of 6 per value);
+// afterwards lane k holds both sums of channel k.  The four waves' sums are added in order and go to
+// partial[block][channel][2]; a second kernel adds the blocks in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void layernorm_cf_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                                   const float* __restrict__ dy, float* __restrict__ dx,
+                                                                   float* __restrict__ partial, int n, int c, long long hw, float eps)
+{
+    __shared__ float2 sred[4][kLnRegC];
+    const long long total = (long long)n * hw;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i0 < total;
+    const long long i = live ? i0 : total - 1;
+    const long long img = i / hw, pix = i - img * hw;
+    const float* xp = x + img * c * hw + pix;
+    const float* gp = dy + img * c * hw + pix;
+    float* dp = dx + img * c * hw + pix;
+    float xv[kLnRegC], gv[kLnRegC];
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) { xv[k] = k < c ? xp[(long long)k * hw] : 0.0f; gv[k] = k < c ? gp[(long long)k * hw] : 0.0f; }
+    float u = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) if (k < c) u += xv[k];
+    u = u / (float)c;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) if (k < c) { const float d = xv[k] - u; s += d * d; }
+    s = s / (float)c;
+    const float rden = 1.0f / sqrtf(s + eps);
+    float mg = 0.0f, mgx = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) if (k < c) {
+        const float xh = (xv[k] - u) * rden, g = gv[k] * weight[k];
+        mg += g; mgx += g * xh;
+    }
+    mg = mg / (float)c; mgx = mgx / (float)c;
+    float v[2 * kLnRegC];
+#pragma unroll
+    for (int k = 0; k < kLnRegC; ++k) {
+        const float xh = (xv[k] - u) * rden, g = gv[k] * (k < c ? weight[k] : 0.0f);
+        if (k < c && live) dp[(long long)k * hw] = (g - mg - xh * mgx) * rden;
+        v[2 * k] = live ? gv[k] * xh : 0.0f;
+        v[2 * k + 1] = live ? gv[k] : 0.0f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#define SRHIP_LN_STEP(M, N) \
+    { \
+        const bool up = (lane & M) != 0; \
+        _Pragma("unroll") for (int j = 0; j < N; ++j) { \
+            const float send = up ? v[j] : v[j + N]; \
+            const float keep = up ? v[j + N] : v[j]; \
+            v[j] = keep + __shfl_xor(send, M); \
+        } \
+    }
+    SRHIP_LN_STEP(32, 64) SRHIP_LN_STEP(16, 32) SRHIP_LN_STEP(8, 16) SRHIP_LN_STEP(4, 8) SRHIP_LN_STEP(2, 4) SRHIP_LN_STEP(1, 2)
+#undef SRHIP_LN_STEP
+    sred[wave][lane] = make_float2(v[0], v[1]);   // lane k: channel k
+    __syncthreads();
+    if (threadIdx.x < kLnRegC) {
+        const int k = threadIdx.x;
+        const float2 a = sred[0][k], b = sred[1][k], d = sred[2][k], e = sred[3][k];
+        float2 t;
+        t.x = ((a.x + b.x) + d.x) + e.x;
+        t.y = ((a.y + b.y) + d.y) + e.y;
+        ((float2*)partial)[(size_t)blockIdx.x * kLnRegC + k] = t;
+    }
+}
+__global__ __launch_bounds__(256) void layernorm_cf_bwd_reg_final_kernel(const float* __restrict__ partial, int nblocks,
+                                                                         float* __restrict__ dweight, float* __restrict__ dbias)
+{
+    __shared__ float sw[256], sb[256];
+    const int k = blockIdx.x;
+    float aw = 0.0f, ab = 0.0f;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        const float2 t = ((const float2*)partial)[(size_t)b * kLnRegC + k];
+        aw += t.x; ab += t.y;
+    }
+    sw[threadIdx.x] = aw; sb[threadIdx.x] = ab;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { sw[threadIdx.x] += sw[threadIdx.x + st]; sb[threadIdx.x] += sb[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { dweight[k] = sw[0]; dbias[k] = sb[0]; }
+}
+
 // pass 2: block (k, slice) sums dy*xh and dy of channel k over its slice of the pixels in a fixed order
 // (strided per-thread sums, then a tree over the block); pass 3 adds the slices in order: deterministic.
 constexpr int kLnSlices = 64;
@@ -2004,19 +2120,40 @@ SRHIP_API size_t srhip_layernorm_cf_bwd_workspace_bytes(int n, int c, int hw)
     return ((size_t)n * hw * 2 + (size_t)c * kLnSlices * 2) * sizeof(float);
 }
 
+// The launches of the backward on a scratch area of (2 n hw + 2 c kLnSlices) floats.  Up to 64 channels: the
+// register-resident form, whose block partials (ceil(n hw / 256) x 64 x 2 floats <= n hw / 2 + 128) fit the same area;
+// every word it reads is written first by the same call.
+static bool ln_force_loops()   // SRHIP_LN_FORM=loops: the channel-loop kernels for every channel count (tests, A/B timing)
+{
+    const char* e = getenv("SRHIP_LN_FORM");
+    return e != nullptr && e[0] == 'l';
+}
+static void layernorm_bwd_launches(const float* x, const float* weight, const float* dy, float* dx, float* dweight, float* dbias,
+                                   float* scratch, int n, int c, int hw, float eps, hipStream_t s)
+{
+    if (c <= kLnRegC && !ln_force_loops()) {
+        const long long nblocks = ((long long)n * hw + 255) / 256;
+        hipLaunchKernelGGL(layernorm_cf_bwd_reg_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, x, weight, dy, dx, scratch, n, c,
+                           (long long)hw, eps);
+        hipLaunchKernelGGL(layernorm_cf_bwd_reg_final_kernel, dim3(c), dim3(256), 0, s, scratch, (int)nblocks, dweight, dbias);
+        return;
+    }
+    float* stats = scratch;
+    float* partial = scratch + (size_t)n * hw * 2;
+    hipLaunchKernelGGL(layernorm_cf_bwd_dx_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0, s,
+                       x, weight, dy, dx, stats, n, c, (long long)hw, eps);
+    hipLaunchKernelGGL(layernorm_cf_bwd_param_kernel, dim3(c, kLnSlices), dim3(256), 0, s, x, dy, stats, partial, n, c, (long long)hw);
+    hipLaunchKernelGGL(layernorm_cf_bwd_final_kernel, dim3(srhip_div_up(c, 64)), dim3(64), 0, s, partial, dweight, dbias, c);
+}
+
 SRHIP_API int srhip_layernorm_cf_bwd_f32(const float* x, const float* weight, const float* dy, float* dx, float* dweight,
                                          float* dbias, void* workspace, int n, int c, int hw, float eps, void* stream)
 {
     SRHIP_REQUIRE(x && weight && dy && dx && dweight && dbias && workspace, "layernorm_cf_bwd_f32: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && hw >= 1, "layernorm_cf_bwd_f32: bad shape");
     SRHIP_REQUIRE(c <= 65535, "layernorm_cf_bwd_f32: at most 65535 channels");
-    hipStream_t s = (hipStream_t)stream;
-    float* stats = (float*)workspace;
-    float* partial = stats + (size_t)n * hw * 2;
-    hipLaunchKernelGGL(layernorm_cf_bwd_dx_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0, s,
-                       x, weight, dy, dx, stats, n, c, (long long)hw, eps);
-    hipLaunchKernelGGL(layernorm_cf_bwd_param_kernel, dim3(c, kLnSlices), dim3(256), 0, s, x, dy, stats, partial, n, c, (long long)hw);
-    hipLaunchKernelGGL(layernorm_cf_bwd_final_kernel, dim3(srhip_div_up(c, 64)), dim3(64), 0, s, partial, dweight, dbias, c);
+    SRHIP_REQUIRE((long long)n * hw < (1ll << 31) * 256, "layernorm_cf_bwd_f32: too many pixels");
+    layernorm_bwd_launches(x, weight, dy, dx, dweight, dbias, (float*)workspace, n, c, hw, eps, (hipStream_t)stream);
     return srhip_check_launch("layernorm_cf_bwd_f32");
 }
 
@@ -2054,15 +2191,9 @@ SRHIP_API int srhip_layernorm_cf_bwd_f32_static(const float* x, const float* wei
         }
         scratch = g_ln_scratch_ptr[dev];
     }
-    hipStream_t s = (hipStream_t)stream;
-    // every word the later kernels read is written first by this call (stats for all n*hw pixels, then all
-    // c * kLnSlices partials): the previous call's contents never need clearing
-    float* stats = scratch;
-    float* partial = scratch + (size_t)n * hw * 2;
-    hipLaunchKernelGGL(layernorm_cf_bwd_dx_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0, s,
-                       x, weight, dy, dx, stats, n, c, (long long)hw, eps);
-    hipLaunchKernelGGL(layernorm_cf_bwd_param_kernel, dim3(c, kLnSlices), dim3(256), 0, s, x, dy, stats, partial, n, c, (long long)hw);
-    hipLaunchKernelGGL(layernorm_cf_bwd_final_kernel, dim3(srhip_div_up(c, 64)), dim3(64), 0, s, partial, dweight, dbias, c);
+    // every word the later kernels read is written first by this call (stats for all n*hw pixels and all c * kLnSlices
+    // partials, or the block partials of the register-resident form): the previous call's contents never need clearing
+    layernorm_bwd_launches(x, weight, dy, dx, dweight, dbias, scratch, n, c, hw, eps, (hipStream_t)stream);
     return srhip_check_launch("layernorm_cf_bwd_f32_static");
 }
 
@@ -2665,8 +2796,12 @@ SRHIP_API int srhip_layernorm_cf_f32(const float* x, const float* weight, const 
 {
     SRHIP_REQUIRE(x && weight && bias && y, "layernorm_cf_f32: null pointer");
     SRHIP_REQUIRE(n >= 1 && c >= 1 && hw >= 1, "layernorm_cf_f32: bad shape");
-    hipLaunchKernelGGL(layernorm_cf_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0,
-                       (hipStream_t)stream, x, weight, bias, y, n, c, (long long)hw, eps);
+    if (c <= kLnRegC && !ln_force_loops())
+        hipLaunchKernelGGL(layernorm_cf_reg_kernel, dim3((unsigned)(((long long)n * hw + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, weight, bias, y, n, c, (long long)hw, eps);
+    else
+        hipLaunchKernelGGL(layernorm_cf_kernel, dim3(grid_for((long long)n * hw, srhip_num_cus())), dim3(kThreads), 0,
+                           (hipStream_t)stream, x, weight, bias, y, n, c, (long long)hw, eps);
     return srhip_check_launch("layernorm_cf_f32");
 }
 

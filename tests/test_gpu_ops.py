@@ -382,6 +382,36 @@ def test_layernorm_cf_backward_golden_and_oracle(F_):
         assert torch.equal(xr.grad, dx) and torch.equal(wr.grad, dw) and torch.equal(br.grad, db)
 
 
+@pytest.mark.parametrize("shape", [(2, 60, 33, 47), (1, 64, 16, 16), (3, 7, 5, 9), (1, 96, 12, 21)])
+def test_layernorm_cf_register_form_equals_the_channel_loops(F_, shape, monkeypatch):
+    """Up to 64 channels the LayerNorm kernels keep a pixel's channels in registers (one pass over x and dy) and reduce the
+    parameter gradients by a butterfly over the wave: y and dx bit-equal to the channel-loop kernels (same operation
+    order per pixel), dweight / dbias equal up to the order of the fp32 sums; also against torch autograd of the formula
+    (CAMixerSR.py:29-37).  96 channels run the channel loops either way."""
+    n, c, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(c + h)
+    x = torch.randn(n, c, h, w, device="cuda", generator=g)
+    wt = torch.rand(c, device="cuda", generator=g) + 0.5
+    b = torch.randn(c, device="cuda", generator=g)
+    dy = torch.randn(n, c, h, w, device="cuda", generator=g)
+    y1 = F_.layernorm_cf(x, wt, b, 1e-6)
+    g1 = F_.layernorm_cf_bwd(x, wt, dy)
+    monkeypatch.setenv("SRHIP_LN_FORM", "loops")
+    y0 = F_.layernorm_cf(x, wt, b, 1e-6)
+    g0 = F_.layernorm_cf_bwd(x, wt, dy)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0) and torch.equal(g1[0], g0[0])
+    for a_, b_ in zip(g1[1:], g0[1:]):
+        assert float((a_ - b_).abs().max()) <= 1e-5 * max(1.0, float(b_.abs().max()))
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    u = xr.mean(1, keepdim=True)
+    s = (xr - u).pow(2).mean(1, keepdim=True)
+    ref = wr[:, None, None] * ((xr - u) / torch.sqrt(s + 1e-6)) + br[:, None, None]
+    ref.backward(dy)
+    for got, want in zip(g1, (xr.grad, wr.grad, br.grad)):
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_layernorm_cf_backward_large_is_deterministic(F_):
     g = torch.Generator(device="cuda").manual_seed(2)
     x = torch.randn(2, 60, 270, 480, device="cuda", generator=g)
