@@ -241,21 +241,29 @@ __global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // grid-sample family.  NHWC bf16: one thread = one output pixel x 8 channels (16 B).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void blend8(const unsigned short* __restrict__ src, long long img_base, int W, int C,
+// Branch-free: every tap is loaded from a clamped (always valid) address and contributes +0 when it lies outside the
+// image, so the four 16-byte loads of a pixel are in flight together (behind a branch per tap each load waited for the
+// one before it).  acc starts at +0 and a sum that started from +0 is never -0, so adding +0 leaves it as skipping the tap
+// would: bit-identical to the branching form.
+__device__ __forceinline__ void blend8(const unsigned short* __restrict__ src, long long img_base, int W, int H, int C,
                                        int c0, const Taps& t, unsigned short* __restrict__ out)
 {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto tap = [&](int y, int x, float wgt) {
-        const uint4 v = *(const uint4*)(src + (img_base + (long long)y * W + x) * C + c0);
-        acc[0] += bf16_lo(v.x) * wgt; acc[1] += bf16_hi(v.x) * wgt;
-        acc[2] += bf16_lo(v.y) * wgt; acc[3] += bf16_hi(v.y) * wgt;
-        acc[4] += bf16_lo(v.z) * wgt; acc[5] += bf16_hi(v.z) * wgt;
-        acc[6] += bf16_lo(v.w) * wgt; acc[7] += bf16_hi(v.w) * wgt;
+    const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0 + 1, 0), W - 1);
+    const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
+    const uint4 v00 = *(const uint4*)(src + (img_base + (long long)ya * W + xa) * C + c0);
+    const uint4 v01 = *(const uint4*)(src + (img_base + (long long)ya * W + xb) * C + c0);
+    const uint4 v10 = *(const uint4*)(src + (img_base + (long long)yb * W + xa) * C + c0);
+    const uint4 v11 = *(const uint4*)(src + (img_base + (long long)yb * W + xb) * C + c0);
+    auto tap = [&](const uint4& v, bool ok, float wgt) {
+        const float e[8] = {bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y), bf16_lo(v.z), bf16_hi(v.z), bf16_lo(v.w), bf16_hi(v.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += ok ? e[j] * wgt : 0.0f;
     };
-    if (t.vy0 && t.vx0) tap(t.y0, t.x0, t.wnw);
-    if (t.vy0 && t.vx1) tap(t.y0, t.x0 + 1, t.wne);
-    if (t.vy1 && t.vx0) tap(t.y0 + 1, t.x0, t.wsw);
-    if (t.vy1 && t.vx1) tap(t.y0 + 1, t.x0 + 1, t.wse);
+    tap(v00, t.vy0 && t.vx0, t.wnw);
+    tap(v01, t.vy0 && t.vx1, t.wne);
+    tap(v10, t.vy1 && t.vx0, t.wsw);
+    tap(v11, t.vy1 && t.vx1, t.wse);
     *(uint4*)out = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
                               pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
 }
@@ -272,7 +280,7 @@ __global__ void upsample_nhwc_kernel(const unsigned short* __restrict__ src, uns
     const float ix = unnorm(coord_val(ax, x), sw, false);
     const float iy = unnorm(coord_val(ay, y), sh, false);
     const Taps t = make_taps(ix, iy, sw, sh);
-    blend8(src, (long long)img * sh * sw, sw, c, g * 8, t, dst + (((long long)img * th + y) * tw + x) * c + g * 8);
+    blend8(src, (long long)img * sh * sw, sw, sh, c, g * 8, t, dst + (((long long)img * th + y) * tw + x) * c + g * 8);
 }
 
 // Integer ratio R = 2 or 4 (the 4x network): one thread = one SOURCE cell x 8 channels = R x R output pixels.  The
@@ -1403,7 +1411,7 @@ __global__ void warp_nhwc_kernel(const unsigned short* __restrict__ frame, const
     if (mode == SRHIP_BILINEAR) {
         const Taps t = make_taps(ix, iy, w, h);
 #pragma unroll
-        for (int k = 0; k < GPT; ++k) blend8(frame, (long long)img * hw, w, c, (g + k) * 8, t, o + k * 8);
+        for (int k = 0; k < GPT; ++k) blend8(frame, (long long)img * hw, w, h, c, (g + k) * 8, t, o + k * 8);
     } else {
         const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
         const bool ok = xn >= 0 && xn < w && yn >= 0 && yn < h;
