@@ -3,6 +3,7 @@
     rocprofv3 --pmc <counters> -- python3 tools/prof_new_kernels.py <case>
 cases: chain (160-160-160-64 1x1 chain at 544x960), chain_res (112-64-64-64 + residual), esa (ESA tail at 540x960 x 48),
 loss (fused clip + L1 + SSIM forward and backward at 16 x 3 x 1024 x 1024), upbwd (x4 up-sampling backward at 16 x 1024 x 1024 x 32),
+ln (channels-first LayerNorm forward + backward at 540 x 960 x 64 fp32), warp16 (bf16 NHWC warp of a 4K 16-channel frame, smooth motion),
 pairbwd (both data gradients of an SRResidualBlock at 16 x 1024 x 1024), pairbits (the forward launch that emits the bits)."""
 import os
 import sys
@@ -34,6 +35,17 @@ elif case == "upbwd":
     y = torch.relu(rnd(16, 256, 256, 32)).to(torch.bfloat16)
     for _ in range(REP):
         F_.upsample_grid_bilinear_bwd_nhwc(dy, 256, 256, relu_out=y)
+elif case == "ln":
+    x, w, b = rnd(1, 64, 540, 960), rnd(64) + 1.0, rnd(64)
+    dy = rnd(1, 64, 540, 960)
+    for _ in range(REP):
+        F_.layernorm_cf(x, w, b, 1e-6)
+        F_.layernorm_cf_bwd(x, w, dy)
+elif case == "warp16":
+    fr = rnd(1, 2160, 3840, 16).to(torch.bfloat16)
+    mv = torch.nn.functional.interpolate(torch.randn(1, 2, 28, 48, device=dev) * 4, size=(2160, 3840), mode="bilinear", align_corners=True)
+    for _ in range(REP):
+        F_.backward_warp_nhwc(fr, mv, "bilinear", True)
 elif case == "esa":
     x, c1, c3 = rnd(1, 540, 960, 48).to(torch.bfloat16), rnd(1, 540, 960, 16).to(torch.bfloat16), rnd(1, 88, 158, 16).to(torch.bfloat16)
     wf, w4 = rnd(16, 16) * 0.3, rnd(48, 16) * 0.3
