@@ -203,6 +203,41 @@ def pixel_shuffle_out(x: Tensor, c: int, r: int) -> Tensor:
     return _PixelShuffleOut.apply(x, c, r)
 
 
+class _PixelShuffle4To16(Function):
+    """(N,h,w,Cs) bf16 -> (N,4h,4w,16) bf16: nn.PixelShuffle(4) written straight into the next convolution's padded input
+    layout (core/models/model_final.py:446-448), and its backward, one pass each."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, c: int):
+        ctx.c, ctx.cs = c, x.shape[-1]
+        return F_.pixel_shuffle4_nhwc_to_nhwc16(x, c)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        return F_.pixel_shuffle4_nhwc16_bwd(dy.contiguous(), ctx.c, ctx.cs), None
+
+
+def pixel_shuffle4_to_nhwc16(x: Tensor, c: int) -> Tensor:
+    return _PixelShuffle4To16.apply(x, c)
+
+
+class _NhwcToNchwF32(Function):
+    """The first c channels of an NHWC bf16 map as an fp32 NCHW tensor (the network's output), one pass each way."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, c: int):
+        ctx.cs = x.shape[-1]
+        return F_.nhwc_bf16_to_nchw_f32(x, c)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        return F_.nchw_f32_to_nhwc_bf16(dy.float().contiguous(), ctx.cs), None
+
+
+def nhwc_to_nchw_f32(x: Tensor, c: int) -> Tensor:
+    return _NhwcToNchwF32.apply(x, c)
+
+
 # ------------------------------------------------------------------------------------------------
 # Any layer functional.conv2d_auto runs (kernel 1 or 3, stride 1 or 2, any channel counts, up to three concatenated
 # sources), differentiable: the temporal network's training graph (core/models/model_final.py under loss.backward()).

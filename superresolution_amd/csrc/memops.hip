@@ -1311,6 +1311,35 @@ __global__ void pixel_shuffle4_nhwc_bf16_to_nhwc16_kernel(const unsigned short* 
     }
 }
 
+// Its backward (autograd of nn.PixelShuffle under loss.backward(), core/trainer.py:160): the gradient of the 16-channel
+// image gathered back into the feature map's layout, dt[n][y][x][k*16 + i*4 + j] = d[n][4y+i][4x+j][k] for k < c, zero in
+// the feature map's other channels.  One lane = one 16-byte chunk of a feature pixel: channels 8q..8q+7 = colour q / 2,
+// sub-rows 2 (q & 1) and 2 (q & 1) + 1, four columns each.
+__global__ void pixel_shuffle4_nhwc16_bwd_kernel(const unsigned short* __restrict__ d, uint4* __restrict__ dt, int n, int c, int h, int w,
+                                                 int cs)
+{
+    const int chunks = cs / 8;
+    const long long total = (long long)n * h * w * chunks;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(it % chunks);
+        const long long pix = it / chunks;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        const int k = q >> 1;
+        if (k < c) {
+            const int x = (int)(pix % w);
+            const long long r = pix / w;                 // (image, y)
+            unsigned a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = 2 * (q & 1) + (e >> 2), j = e & 3;
+                a[e] = (unsigned)d[((r * 4 + i) * (4ll * w) + 4 * x + j) * 16 + k];
+            }
+            o = make_uint4(a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16));
+        }
+        dt[it] = o;
+    }
+}
+
 // The tail of the temporal network (core/models/model_final.py:446-449: PixelShuffle(4) -> Conv2d(3, 3, 3, 1, 1) -> ReLU)
 // in one pass: src (N,h,w,cs >= 48) bf16 NHWC, channel k*16 + i*4 + j = colour k of output pixel (4y+i, 4x+j);
 // dst (N,3,4h,4w) fp32 NCHW = act(conv3x3(shuffled) + bias).  The shuffled image never exists: a work-group stages an
@@ -2761,6 +2790,19 @@ SRHIP_API int srhip_pixel_shuffle4_conv3x3_c3_nchw_f32(const void* src, const fl
     hipLaunchKernelGGL(pixel_shuffle4_conv3x3_c3_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)src, weight, bias, dst, n, h, w, cstride, s);
     return srhip_check_launch("pixel_shuffle4_conv3x3_c3_nchw_f32");
+}
+
+SRHIP_API int srhip_pixel_shuffle4_nhwc16_bwd_bf16(const void* d, void* dt, int n, int c, int h, int w, int cstride, void* stream)
+{
+    SRHIP_REQUIRE(d && dt, "pixel_shuffle4_nhwc16_bwd_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && h >= 1 && w >= 1, "pixel_shuffle4_nhwc16_bwd_bf16: bad shape");
+    SRHIP_REQUIRE(c >= 1 && c <= 4 && cstride >= 16 * c && cstride % 8 == 0,
+                  "pixel_shuffle4_nhwc16_bwd_bf16: 1 to 4 colours, feature pixels of at least 16 c channels (a multiple of 8)");
+    SRHIP_REQUIRE((size_t)dt % 16 == 0, "pixel_shuffle4_nhwc16_bwd_bf16: aligned tensors");
+    const long long work = (long long)n * h * w * (cstride / 8);
+    hipLaunchKernelGGL(pixel_shuffle4_nhwc16_bwd_kernel, dim3(grid_for(work, srhip_num_cus())), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const unsigned short*)d, (uint4*)dt, n, c, h, w, cstride);
+    return srhip_check_launch("pixel_shuffle4_nhwc16_bwd_bf16");
 }
 
 SRHIP_API int srhip_pixel_shuffle4_nhwc_bf16_to_nhwc16(const void* src, void* dst, int n, int c, int h, int w, int cstride, void* stream)

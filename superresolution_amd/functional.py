@@ -970,6 +970,17 @@ def pixel_shuffle4_nhwc_to_nhwc16(x: torch.Tensor, c: int) -> torch.Tensor:
     return out
 
 
+def pixel_shuffle4_nhwc16_bwd(d: torch.Tensor, c: int, cs: int) -> torch.Tensor:
+    """Backward of pixel_shuffle4_nhwc_to_nhwc16: d (N,4h,4w,16) bf16 -> (N,h,w,cs) bf16 (zero outside the first 16c channels)."""
+    d = _req(d, torch.bfloat16, "d")
+    n, hh, ww, c16 = d.shape
+    if c16 != 16 or hh % 4 or ww % 4 or not 1 <= c <= 4 or cs < 16 * c or cs % 8:
+        raise ValueError("pixel_shuffle4_nhwc16_bwd: d must be (N,4h,4w,16), 1 <= c <= 4, cs >= 16 c a multiple of 8")
+    out = torch.empty((n, hh // 4, ww // 4, cs), dtype=torch.bfloat16, device=d.device)
+    check(lib.srhip_pixel_shuffle4_nhwc16_bwd_bf16(d.data_ptr(), out.data_ptr(), n, c, hh // 4, ww // 4, cs, _stream()))
+    return out
+
+
 def pixel_shuffle4_conv3x3_c3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
                               slope: float = 0.0) -> torch.Tensor:
     """act(conv2d(pixel_shuffle(x, 4), weight, bias, padding=1)) for a 3 -> 3 channel 3x3 layer, in one pass:

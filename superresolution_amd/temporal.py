@@ -465,10 +465,17 @@ class SuperSampler(nn.Module):
         c0, c2 = self.conv_out[0], self.conv_out[2]
         if training:
             t = _rec("conv_out.0", A_.conv2d((fmap, fmap_shadow), c0.weight, c0.bias), c0.out_channels)
-            hr = A_.pixel_shuffle_out(t, self.frame_ch, self.sr_scale)                         # (b, 3, H, W) fp32
-            x16 = nn.functional.pad(hr.permute(0, 2, 3, 1), (0, 16 - self.frame_ch)).to(torch.bfloat16).contiguous()
-            y = _rec("conv_out.2", A_.conv2d(x16, c2.weight, c2.bias, act=F_.ACT_RELU), self.frame_ch)
-            sr_frame = y[..., :self.frame_ch].permute(0, 3, 1, 2).float()
+            if self.sr_scale == 4 and self.frame_ch <= 4 and _TRACE is None:
+                # PixelShuffle straight into the last layer's padded input layout, and the output's layout change as one
+                # pass (each with a one-pass backward) instead of permute / pad / cast chains on the 16-channel HR image
+                x16 = A_.pixel_shuffle4_to_nhwc16(t, self.frame_ch)
+                y = A_.conv2d(x16, c2.weight, c2.bias, act=F_.ACT_RELU)
+                sr_frame = A_.nhwc_to_nchw_f32(y, self.frame_ch)
+            else:
+                hr = A_.pixel_shuffle_out(t, self.frame_ch, self.sr_scale)                     # (b, 3, H, W) fp32
+                x16 = nn.functional.pad(hr.permute(0, 2, 3, 1), (0, 16 - self.frame_ch)).to(torch.bfloat16).contiguous()
+                y = _rec("conv_out.2", A_.conv2d(x16, c2.weight, c2.bias, act=F_.ACT_RELU), self.frame_ch)
+                sr_frame = y[..., :self.frame_ch].permute(0, 3, 1, 2).float()
             assert depth_max < 10, "Depth value is too large"
             return sr_frame, enhance_weight
         t = F_.conv2d_auto((fmap, fmap_shadow), c0.weight, c0.bias)

@@ -402,3 +402,35 @@ def test_enhance_weighted_l1_vs_torch(case):
     assert float((a.grad - b.grad).abs().max()) <= 2e-7 * float(b.grad.abs().max())
     assert float(a.grad[:, :, ::3, ::5].abs().max()) == 0.0
     assert torch.equal(loss, loss2) and torch.equal(a.grad, a2.grad)
+
+
+@pytest.mark.parametrize("case", [(2, 5, 7, 48, 3), (1, 3, 9, 64, 4), (1, 8, 8, 16, 1)])
+def test_pixel_shuffle4_to_nhwc16_and_output_layout_are_differentiable_permutations(case):
+    """nn.PixelShuffle(4) written into the next layer's 16-channel NHWC input (core/models/model_final.py:446-448) and the
+    network output's NHWC bf16 -> NCHW fp32 change, each with its one-pass backward: values and gradients bit-equal to the
+    torch formulation (pixel_shuffle, permute, pad, casts) on the same bf16 data."""
+    from superresolution_amd import autograd_ops as A_
+    n, h, w, cs, c = case
+    g = torch.Generator().manual_seed(cs + c)
+    t = ((torch.rand(n, h, w, cs, generator=g) - 0.5) * 4).to(torch.bfloat16).cuda()
+    dy = ((torch.rand(n, 4 * h, 4 * w, 16, generator=g) - 0.5) * 4).to(torch.bfloat16).cuda()
+    a = t.clone().requires_grad_(True)
+    y = A_.pixel_shuffle4_to_nhwc16(a, c)
+    y.backward(dy)
+    b = t.clone().requires_grad_(True)
+    hr = torch.nn.functional.pixel_shuffle(b[..., :16 * c].permute(0, 3, 1, 2).float(), 4)          # (n, c, 4h, 4w)
+    ref = torch.nn.functional.pad(hr.permute(0, 2, 3, 1), (0, 16 - c)).to(torch.bfloat16)
+    ref.backward(dy)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and torch.equal(a.grad, b.grad)
+    # output side
+    x = ((torch.rand(n, 4 * h, 4 * w, 16, generator=g) - 0.5) * 4).to(torch.bfloat16).cuda()
+    d = torch.rand(n, c, 4 * h, 4 * w, generator=g).cuda()
+    xa = x.clone().requires_grad_(True)
+    o = A_.nhwc_to_nchw_f32(xa, c)
+    o.backward(d)
+    xb = x.clone().requires_grad_(True)
+    oref = xb[..., :c].permute(0, 3, 1, 2).float()
+    oref.backward(d)
+    torch.cuda.synchronize()
+    assert torch.equal(o, oref) and torch.equal(xa.grad, xb.grad)
