@@ -444,6 +444,11 @@ SRHIP_API int srhip_pixel_shuffle4_nhwc_bf16_to_nhwc16(const void* src, void* ds
  * d (N,4h,4w,16) bf16 = gradient of the 16-channel image -> dt (N,h,w,cstride) bf16 = gradient of the feature map,
  * dt[..., k*16 + i*4 + j] = d[4y+i, 4x+j, k] for k < c, zero in the other channels.  Bit-exact (a permutation). */
 SRHIP_API int srhip_pixel_shuffle4_nhwc16_bwd_bf16(const void* d, void* dt, int n, int c, int h, int w, int cstride, void* stream);
+
+/* (N,ho,wo,C) bf16 NHWC -> (N,h,w,C) with the input at the even positions and zeros elsewhere (ho = ceil(h/2), wo =
+ * ceil(w/2), C a multiple of 8): the output gradient of a 3x3 / stride 2 / pad 1 layer (core/models/model_final.py:272-276
+ * under loss.backward(), core/trainer.py:160) as the gradient of the stride-1 layer it is a 2 x 2 pick of.  Bit-exact. */
+SRHIP_API int srhip_zero_insert2_nhwc_bf16(const void* src, void* dst, int n, int ho, int wo, int h, int w, int c, void* stream);
 /* The whole tail nn.PixelShuffle(4) -> nn.Conv2d(3, 3, 3, 1, 1) -> activation of core/models/model_final.py:446-449 in
  * one pass: src (N,h,w,cstride >= 48) bf16 NHWC, channel k*16 + i*4 + j; weight fp32 (3,3,3,3) OIHW and bias fp32[3]
  * (or NULL) in device memory, used as they are (fp32 arithmetic); dst (N,3,4h,4w) fp32 NCHW.

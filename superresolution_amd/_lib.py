@@ -137,6 +137,7 @@ _SIGNATURES = {
     "srhip_pixel_shuffle4_conv3x3_c3_nchw_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
     "srhip_pixel_shuffle4_nhwc_bf16_to_nhwc16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "srhip_pixel_shuffle4_nhwc16_bwd_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "srhip_zero_insert2_nhwc_bf16": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_pixel_unshuffle4_nchw_f32_to_nhwc_bf16_max": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, c_int, c_void_p]),
     "srhip_pixel_unshuffle": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_pixel_shuffle_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

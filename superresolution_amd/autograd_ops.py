@@ -250,6 +250,8 @@ def _tile_channels(c: int) -> int:
 def _zero_insert2(dz: Tensor, h: int, w: int) -> Tensor:
     """(N,ho,wo,C) -> (N,h,w,C) with dz at the even positions: a stride-2 layer's output gradient seen from the
     stride-1 layer it is a 2x2 pick of (its data and weight gradients are that layer's on this tensor)."""
+    if dz.dtype == torch.bfloat16 and dz.shape[-1] % 8 == 0 and dz.is_contiguous():
+        return F_.zero_insert2_nhwc(dz, h, w)   # one pass instead of a fill and a strided copy
     up = torch.zeros((dz.shape[0], h, w, dz.shape[-1]), dtype=dz.dtype, device=dz.device)
     up[:, ::2, ::2] = dz
     return up

@@ -1340,6 +1340,24 @@ __global__ void pixel_shuffle4_nhwc16_bwd_kernel(const unsigned short* __restric
     }
 }
 
+// (N,ho,wo,C) -> (N,h,w,C) with the input at the even positions and zeros elsewhere: the output gradient of a stride-2
+// layer (core/models/model_final.py:272-276 under loss.backward()) seen from the stride-1 layer it is a 2 x 2 pick of.
+__global__ void zero_insert2_nhwc_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int ho, int wo, int h, int w,
+                                         int chunks, long long total)
+{
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(it % chunks);
+        long long t = it / chunks;
+        const int x = (int)(t % w);
+        t /= w;
+        const int y = (int)(t % h);
+        const long long img = t / h;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (((x | y) & 1) == 0) o = src[((img * ho + (y >> 1)) * wo + (x >> 1)) * chunks + q];
+        dst[it] = o;
+    }
+}
+
 // The tail of the temporal network (core/models/model_final.py:446-449: PixelShuffle(4) -> Conv2d(3, 3, 3, 1, 1) -> ReLU)
 // in one pass: src (N,h,w,cs >= 48) bf16 NHWC, channel k*16 + i*4 + j = colour k of output pixel (4y+i, 4x+j);
 // dst (N,3,4h,4w) fp32 NCHW = act(conv3x3(shuffled) + bias).  The shuffled image never exists: a work-group stages an
@@ -2790,6 +2808,18 @@ SRHIP_API int srhip_pixel_shuffle4_conv3x3_c3_nchw_f32(const void* src, const fl
     hipLaunchKernelGGL(pixel_shuffle4_conv3x3_c3_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)src, weight, bias, dst, n, h, w, cstride, s);
     return srhip_check_launch("pixel_shuffle4_conv3x3_c3_nchw_f32");
+}
+
+SRHIP_API int srhip_zero_insert2_nhwc_bf16(const void* src, void* dst, int n, int ho, int wo, int h, int w, int c, void* stream)
+{
+    SRHIP_REQUIRE(src && dst, "zero_insert2_nhwc_bf16: null pointer");
+    SRHIP_REQUIRE(n >= 1 && ho >= 1 && wo >= 1 && c >= 8 && c % 8 == 0, "zero_insert2_nhwc_bf16: bad shape (channels in multiples of 8)");
+    SRHIP_REQUIRE((h + 1) / 2 == ho && (w + 1) / 2 == wo, "zero_insert2_nhwc_bf16: (%d x %d) is not the even positions of (%d x %d)", ho, wo, h, w);
+    SRHIP_REQUIRE(((size_t)src | (size_t)dst) % 16 == 0, "zero_insert2_nhwc_bf16: aligned tensors");
+    const long long total = (long long)n * h * w * (c / 8);
+    hipLaunchKernelGGL(zero_insert2_nhwc_kernel, dim3(grid_for(total, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)src, (uint4*)dst, ho, wo, h, w, c / 8, total);
+    return srhip_check_launch("zero_insert2_nhwc_bf16");
 }
 
 SRHIP_API int srhip_pixel_shuffle4_nhwc16_bwd_bf16(const void* d, void* dt, int n, int c, int h, int w, int cstride, void* stream)

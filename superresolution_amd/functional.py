@@ -970,6 +970,15 @@ def pixel_shuffle4_nhwc_to_nhwc16(x: torch.Tensor, c: int) -> torch.Tensor:
     return out
 
 
+def zero_insert2_nhwc(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """(N,ho,wo,C) bf16 -> (N,h,w,C) with x at the even positions and zeros elsewhere (ho = ceil(h/2), wo = ceil(w/2))."""
+    x = _req(x, torch.bfloat16, "x")
+    n, ho, wo, c = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=x.device)
+    check(lib.srhip_zero_insert2_nhwc_bf16(x.data_ptr(), out.data_ptr(), n, ho, wo, h, w, c, _stream()))
+    return out
+
+
 def pixel_shuffle4_nhwc16_bwd(d: torch.Tensor, c: int, cs: int) -> torch.Tensor:
     """Backward of pixel_shuffle4_nhwc_to_nhwc16: d (N,4h,4w,16) bf16 -> (N,h,w,cs) bf16 (zero outside the first 16c channels)."""
     d = _req(d, torch.bfloat16, "d")

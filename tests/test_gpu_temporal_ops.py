@@ -434,3 +434,15 @@ def test_pixel_shuffle4_to_nhwc16_and_output_layout_are_differentiable_permutati
     oref.backward(d)
     torch.cuda.synchronize()
     assert torch.equal(o, oref) and torch.equal(xa.grad, xb.grad)
+
+
+@pytest.mark.parametrize("case", [(2, 7, 9, 32), (1, 8, 8, 64), (1, 1, 5, 8)])
+def test_zero_insert2_places_the_gradient_at_the_even_positions(F_, case):
+    n, h, w, c = case
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    x = torch.randn(n, ho, wo, c).to(torch.bfloat16).cuda()
+    got = F_.zero_insert2_nhwc(x, h, w)
+    ref = torch.zeros(n, h, w, c, dtype=torch.bfloat16, device="cuda")
+    ref[:, ::2, ::2] = x
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
