@@ -279,6 +279,10 @@ typedef struct {
 } srhip_wgrad_job;
 SRHIP_API int srhip_conv3x3_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w,
                                         int ci_pad, int co_pad, int w_i, int accumulate, float scale, void* stream);
+/* The same for 1x1 layers (core/models/model_final.py:237-246): dw_j[co][ci_off + ci] of an fp32 (O, w_i, 1, 1) gradient --
+ * the centre tap alone (one accumulator tile per wave instead of nine). */
+SRHIP_API int srhip_conv1x1_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w,
+                                        int ci_pad, int co_pad, int w_i, int accumulate, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Generic direct convolution (any kernel size / stride / padding, NHWC bf16,

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "srhip_conv3x3_wgrad": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float, c_void_p]),
     "srhip_conv3x3_wgrad_windows": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_float] + [c_int] * 4 + [c_void_p]),
     "srhip_conv3x3_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
+    "srhip_conv1x1_wgrad_multi": (c_int, [ctypes.POINTER(WgradJob), c_int, c_void_p] + [c_int] * 7 + [c_float, c_void_p]),
     "srhip_conv2d_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 +
                             [c_int, c_float, c_float, c_void_p]),
     "srhip_upsample_grid_bilinear_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

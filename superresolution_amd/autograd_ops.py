@@ -303,7 +303,10 @@ def _auto_wgrad(srcs, dzs: Tensor, w: Tensor):
     slower than that).  The kernel reads the channel windows in place: no slice of x or dz is copied out."""
     cout, cin, k, _ = w.shape
     # (every entry is written: the slice pairs tile the whole weight, the first input slice's jobs the whole bias)
-    dw3 = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=w.device)
+    # (a 1x1 layer: the kernel's centre-tap form writes the (O,I,1,1) gradient directly; SRHIP_NO_WGRAD_1X1=1: as the centre
+    # tap of the 3x3 result, eight taps computed and dropped)
+    k_out = 1 if (k == 1 and os.environ.get("SRHIP_NO_WGRAD_1X1", "0") != "1") else 3
+    dw3 = torch.empty((cout, cin, k_out, k_out), dtype=torch.float32, device=w.device)
     db = torch.empty((cout,), dtype=torch.float32, device=w.device)
     dz_slices = [(o, min(64, cout - o)) for o in range(0, cout, 64)]
     # all slice pairs of one tile shape go out together (one gradient launch + one reduction per group of <= 32 pairs
@@ -325,7 +328,7 @@ def _auto_wgrad(srcs, dzs: Tensor, w: Tensor):
     for (ci_tile, co_tile), jobs in groups.items():
         for b in range(0, len(jobs), batch):
             F_.conv3x3_wgrad_multi(jobs[b:b + batch], dw3, db, ci_tile, co_tile)
-    return (dw3 if k == 3 else dw3[:, :, 1:2, 1:2].contiguous()), db
+    return (dw3 if k == k_out else dw3[:, :, 1:2, 1:2].contiguous()), db
 
 
 def _dgrad_rows(dzs: Tensor, w: Tensor, row0: int, rows: int, mask: Tensor = None) -> Tensor:

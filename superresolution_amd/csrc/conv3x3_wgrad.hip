@@ -59,15 +59,21 @@ struct ReduceParams {
     int cit_n, nt, w_i, accumulate;
     float scale;
     int nwblocks, blocks_per_job;
+    int tap0, ntaps, dw_taps;   // partial tiles [tap0, tap0 + ntaps) -> dw[co][ci][dw_taps] (9: tap index = position; 1: position 0)
     WgradOut out[kMaxJobs];
 };
 
 constexpr int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
 constexpr unsigned kOob = 0x80000000u;
 
-template <int CI_, int CO_>
+// TAPS = 9: the 3x3 layer.  TAPS = 1: a 1x1 layer (core/models/model_final.py:237-246) = the centre tap alone -- one
+// accumulator tile instead of nine, 8 MFMAs per row and wave instead of 72 (as the centre tap of the full kernel a 1x1
+// layer paid for eight taps it threw away).
+template <int CI_, int CO_, int TAPS_ = 9>
 struct WCfg {
-    static constexpr int CI = CI_, CO = CO_;
+    static constexpr int CI = CI_, CO = CO_, TAPS = TAPS_;
+    static constexpr int KX0 = TAPS == 9 ? 0 : 1, KX1 = TAPS == 9 ? 3 : 2;   // tap columns walked
+    static_assert(TAPS == 9 || TAPS == 1, "3x3 or its centre tap");
     static constexpr int NWAVES = 4, TW = 128;
     static constexpr int CIT = CI >= 32 ? CI / 32 : 1;
     static constexpr int COT = CO >= 32 ? CO / 32 : 1;
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;   // (TAPS = 1 touches acc[4] only: the others are dead code)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.0f;
     bf16x8 ones;
@@ -314,16 +320,17 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                 ahi[PH][sk] = lds_read_tr<sk * 16 * C::ZPB>(za[1]);
             });
             // x fragments run two steps ahead of the MFMAs
-            constexpr int NSTEP = 3 * C::NKS;
-            constexpr int NP = C::MAXPX + C::MAXPZ, PPS = (NP + NSTEP - 1) / NSTEP;
+            // steps [ST0, NSTEP) = (tap column kx, k-step): all three columns, or the centre column alone
+            constexpr int ST0 = C::KX0 * C::NKS, NSTEP = C::KX1 * C::NKS;
+            constexpr int NP = C::MAXPX + C::MAXPZ, PPS = (NP + (NSTEP - ST0) - 1) / (NSTEP - ST0);
             bf16x4 blo[3], bhi[3];
-            wg_static_for<0, 2>([&](auto st_c) {
+            wg_static_for<ST0, ST0 + 2>([&](auto st_c) {
                 SRHIP_CAPTURE(blo); SRHIP_CAPTURE(bhi);
                 constexpr int st = decltype(st_c)::value;
-                blo[st] = lds_read_tr<(st % C::NKS) * 16 * C::XPB>(xa[st / C::NKS][0]);
-                bhi[st] = lds_read_tr<(st % C::NKS) * 16 * C::XPB>(xa[st / C::NKS][1]);
+                blo[st % 3] = lds_read_tr<(st % C::NKS) * 16 * C::XPB>(xa[st / C::NKS][0]);
+                bhi[st % 3] = lds_read_tr<(st % C::NKS) * 16 * C::XPB>(xa[st / C::NKS][1]);
             });
-            wg_static_for<0, NSTEP>([&](auto st_c) {
+            wg_static_for<ST0, NSTEP>([&](auto st_c) {
                 SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi); SRHIP_CAPTURE(acc); SRHIP_CAPTURE(accb); SRHIP_CAPTURE(blo); SRHIP_CAPTURE(bhi);
                 constexpr int st = decltype(st_c)::value;
                 constexpr int kx = st / C::NKS, sk = st % C::NKS;
@@ -338,14 +345,14 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                 } else {
                     wg_lds_wait<0>();   // nothing stays in flight across the end of a row
                 }
-                if constexpr (st == 0) {  // the dz reads are older than every x read
+                if constexpr (st == ST0) {  // the dz reads are older than every x read
 #pragma unroll
                     for (int k = 0; k < C::NKS; ++k) { SRHIP_LOAD_FENCE(alo[PH][k]); SRHIP_LOAD_FENCE(ahi[PH][k]); }
                 }
                 SRHIP_LOAD_FENCE(blo[cur]);  // consumers stay behind the wait
                 SRHIP_LOAD_FENCE(bhi[cur]);
                 const bf16x8 b = join(blo[cur], bhi[cur]);
-                wg_static_for<0, 3>([&](auto ky_c) {
+                wg_static_for<(C::TAPS == 9 ? 0 : 1), (C::TAPS == 9 ? 3 : 2)>([&](auto ky_c) {
                     SRHIP_CAPTURE(alo); SRHIP_CAPTURE(ahi); SRHIP_CAPTURE(acc);
                     constexpr int ky = decltype(ky_c)::value;
                     constexpr int sl = (PH + 3 - ky) % 3;    // dz row r - ky
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
                     if (cit == sk % C::CIT) wg_mfma<9>(accb, join(alo[PH][sk], ahi[PH][sk]), ones);
                 }
                 // the LDS-DMA pieces of the rows two iterations ahead, spread over the first steps
-                wg_static_for<st * PPS, ((st + 1) * PPS < NP ? (st + 1) * PPS : NP)>([&](auto m_c) {
+                wg_static_for<(st - ST0) * PPS, ((st - ST0 + 1) * PPS < NP ? (st - ST0 + 1) * PPS : NP)>([&](auto m_c) {
                     issue_piece(WIntC<decltype(m_c)::value + 0 * st>{}, dxs, dxslot, dzs, dzslot);
                 });
             });
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(C::NWAVES * 64, 1) void conv3x3_wgrad_kernel(const 
     // ---- partial tiles -> workspace [workgroup][wave][10][16 registers][64 lanes]
     float* out = p.partial + ((size_t)(blockIdx.x * C::NWAVES + wave) * 10) * 1024 + lane;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = (C::TAPS == 9 ? 0 : 4); t < (C::TAPS == 9 ? 9 : 5); ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = acc[t][r];
 #pragma unroll
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const ReduceParams r
     if (jblock < nwblocks) {
         int b = jblock;
         const int q = b & 3; b >>= 2;
-        const int tap = b % 9, tile = b / 9;
+        const int tap = rp.tap0 + b % rp.ntaps, tile = b / rp.ntaps;
         const int cot = tile / cit_n, cit = tile - cot * cit_n;
         if (32 * cot + 8 * q >= co_real) return;   // the quarter's rows are all padding (uniform over the block)
         const int l64 = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const ReduceParams r
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (ci0 + j < ci_real) {
-                    float* dst = dw + ((size_t)co * w_i + ci_off + ci0 + j) * 9 + tap;
+                    float* dst = dw + ((size_t)co * w_i + ci_off + ci0 + j) * rp.dw_taps + (rp.dw_taps == 9 ? tap : 0);
                     *dst = accumulate ? *dst + tv[j] : tv[j];
                 }
         }
@@ -524,7 +531,8 @@ int launch_wgrad(WgradParams p, const WgradOut* outs, int w_i, int accumulate, f
     rp.partial = p.partial;
     rp.nwg = p.wgs_per_job;
     rp.cit_n = C::CIT; rp.nt = C::NT; rp.w_i = w_i; rp.accumulate = accumulate; rp.scale = scale;
-    rp.nwblocks = C::NT * 9 * 4;
+    rp.tap0 = C::TAPS == 9 ? 0 : 4; rp.ntaps = C::TAPS; rp.dw_taps = C::TAPS;
+    rp.nwblocks = C::NT * C::TAPS * 4;
     rp.blocks_per_job = rp.nwblocks + C::COT;   // + one bias block per 32 output channels
     for (int j = 0; j < p.njobs; ++j) rp.out[j] = outs[j];
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rp.blocks_per_job * p.njobs), dim3(1024), 0, stream, rp);
@@ -540,8 +548,8 @@ SRHIP_API size_t srhip_conv3x3_wgrad_workspace_bytes(void)
     return (size_t)srhip_num_cus() * 4 * 10 * 1024 * sizeof(float);
 }
 
-SRHIP_API int srhip_conv3x3_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w,
-                                        int ci_pad, int co_pad, int w_i, int accumulate, float scale, void* stream)
+static int wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w, int ci_pad, int co_pad,
+                       int w_i, int accumulate, float scale, int taps, void* stream)
 {
     SRHIP_REQUIRE(jobs && workspace, "conv3x3_wgrad: null pointer");
     SRHIP_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, "conv3x3_wgrad: %d jobs (1 .. %d per call)", njobs, kMaxJobs);
@@ -568,7 +576,9 @@ SRHIP_API int srhip_conv3x3_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, 
     for (int j = njobs; j < kMaxJobs; ++j) { p.jobs[j] = p.jobs[0]; }
     hipStream_t s = (hipStream_t)stream;
 #define SRHIP_WGRAD_CASE(CI, CO) \
-    if (ci_pad == CI && co_pad == CO) return launch_wgrad<WCfg<CI, CO>>(p, outs, w_i, accumulate, scale, s);
+    if (ci_pad == CI && co_pad == CO) \
+        return taps == 9 ? launch_wgrad<WCfg<CI, CO, 9>>(p, outs, w_i, accumulate, scale, s) \
+                         : launch_wgrad<WCfg<CI, CO, 1>>(p, outs, w_i, accumulate, scale, s);
     SRHIP_WGRAD_CASE(64, 64)
     SRHIP_WGRAD_CASE(32, 64)
     SRHIP_WGRAD_CASE(16, 64)
@@ -581,6 +591,18 @@ SRHIP_API int srhip_conv3x3_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, 
 #undef SRHIP_WGRAD_CASE
     srhip_set_error("conv3x3_wgrad: unsupported padded channels ci=%d co=%d (each must be 16, 32 or 64)", ci_pad, co_pad);
     return SRHIP_ERR_INVALID;
+}
+
+SRHIP_API int srhip_conv3x3_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w,
+                                        int ci_pad, int co_pad, int w_i, int accumulate, float scale, void* stream)
+{
+    return wgrad_multi(jobs, njobs, workspace, n, h, w, ci_pad, co_pad, w_i, accumulate, scale, 9, stream);
+}
+
+SRHIP_API int srhip_conv1x1_wgrad_multi(const srhip_wgrad_job* jobs, int njobs, void* workspace, int n, int h, int w,
+                                        int ci_pad, int co_pad, int w_i, int accumulate, float scale, void* stream)
+{
+    return wgrad_multi(jobs, njobs, workspace, n, h, w, ci_pad, co_pad, w_i, accumulate, scale, 1, stream);
 }
 
 SRHIP_API int srhip_conv3x3_wgrad_windows(const void* x, const void* dz, float* dw, float* db, void* workspace, int n, int h,

@@ -317,12 +317,14 @@ def conv3x3_wgrad_multi(jobs, dw: torch.Tensor, db: Optional[torch.Tensor], ci_t
     (x, x_first_channel, ci_real, ci_off, dz, dz_first_channel, co_real, co_off, with_bias): job j fills
     dw[co_off : co_off + co_real, ci_off : ci_off + ci_real] from channels [x_first_channel, + ci_tile) of the map x and
     [dz_first_channel, + co_tile) of the map dz (tiles 16, 32 or 64; a window may reach past its map's last channel), and,
-    with_bias, db[co_off : co_off + co_real].  All maps share (N, H, W)."""
+    with_bias, db[co_off : co_off + co_real].  All maps share (N, H, W).  dw is the fp32 gradient of a (O,I,3,3) weight,
+    or of a (O,I,1,1) weight (srhip_conv1x1_wgrad_multi: the centre tap alone)."""
     from ._lib import WgradJob
     if not 1 <= len(jobs) <= WGRAD_MAX_JOBS:
         raise ValueError("conv3x3_wgrad_multi: 1 .. %d jobs per call" % WGRAD_MAX_JOBS)
-    if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.dim() != 4 or tuple(dw.shape[2:]) != (3, 3):
-        raise ValueError("conv3x3_wgrad_multi: dw must be a contiguous fp32 (O,I,3,3) tensor")
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.dim() != 4 or tuple(dw.shape[2:]) not in ((3, 3), (1, 1)):
+        raise ValueError("conv3x3_wgrad_multi: dw must be a contiguous fp32 (O,I,3,3) or (O,I,1,1) tensor")
+    taps = dw.shape[2] * dw.shape[3]
     if db is not None and (db.dtype != torch.float32 or not db.is_contiguous() or db.numel() < dw.shape[0]):
         raise ValueError("conv3x3_wgrad_multi: db must be fp32[O]")
     arr = (WgradJob * len(jobs))()
@@ -339,13 +341,14 @@ def conv3x3_wgrad_multi(jobs, dw: torch.Tensor, db: Optional[torch.Tensor], ci_t
             raise ValueError("conv3x3_wgrad_multi: output-channel slice outside dw")
         a = arr[j]
         a.x, a.dz = x.data_ptr(), dz.data_ptr()
-        a.dw = dw.data_ptr() + co_off * w_i * 9 * 4
+        a.dw = dw.data_ptr() + co_off * w_i * taps * 4
         a.db = (db.data_ptr() + co_off * 4) if (with_bias and db is not None) else None
         a.ci_real, a.ci_off, a.co_real = ci_real, ci_off, co_real
         a.x_cstride, a.x_coff, a.dz_cstride, a.dz_coff, a.reserved = x.shape[3], xo, dz.shape[3], zo, 0
     n, h, w = shape
-    check(lib.srhip_conv3x3_wgrad_multi(arr, len(jobs), _wgrad_workspace(jobs[0][0].device).data_ptr(), n, h, w, ci_tile, co_tile,
-                                        w_i, int(accumulate), scale, _stream()))
+    entry = lib.srhip_conv3x3_wgrad_multi if taps == 9 else lib.srhip_conv1x1_wgrad_multi
+    check(entry(arr, len(jobs), _wgrad_workspace(jobs[0][0].device).data_ptr(), n, h, w, ci_tile, co_tile, w_i, int(accumulate),
+                scale, _stream()))
 
 
 def relu_mask(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -134,6 +134,36 @@ def test_wgrad_of_a_wide_layer_in_batched_jobs_vs_oracle(F_, case, monkeypatch):
     assert relerr(dw.cpu().numpy(), dw1.cpu().numpy()) <= 1e-5 and relerr(db.cpu().numpy(), db1.cpu().numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("case", [((160,), 160, 2, 9, 70), ((112,), 64, 1, 20, 33), ((64,), 16, 1, 7, 130), ((32, 64), 48, 1, 5, 9)])
+def test_wgrad_of_1x1_layers_on_the_centre_tap_form(F_, case, monkeypatch):
+    """1x1 layers (core/models/model_final.py:237-246): the weight-gradient kernel's one-tap form against the CPU oracle and
+    against the centre tap of the full 3x3 result."""
+    from superresolution_amd import autograd_ops as A_
+    srcs_c, cout, n, h, w = case
+    cin = sum(srcs_c)
+    rng = np.random.default_rng(cin * 3 + cout)
+    x = bf16r(rng.standard_normal((n, cin, h, w)))
+    dy = bf16r(rng.standard_normal((n, cout, h, w)))
+    dw_ref, db_ref = orc.conv2d_bwd_weight(x, dy, (cout, cin, 1, 1), padding=0)
+    maps, k0 = [], 0
+    for c in srcs_c:
+        m = torch.zeros(n, h, w, F_.pad16(c), dtype=torch.bfloat16)
+        m[..., :c] = torch.from_numpy(x[:, k0:k0 + c]).permute(0, 2, 3, 1).to(torch.bfloat16)
+        maps.append(m.cuda())
+        k0 += c
+    dz = torch.zeros(n, h, w, F_.pad16(cout), dtype=torch.bfloat16)
+    dz[..., :cout] = torch.from_numpy(dy).permute(0, 2, 3, 1).to(torch.bfloat16)
+    dz = dz.cuda()
+    wt = torch.zeros(cout, cin, 1, 1, device="cuda")
+    dw, db = A_._auto_wgrad(tuple(maps), dz, wt)
+    monkeypatch.setenv("SRHIP_NO_WGRAD_1X1", "1")
+    dw3, db3 = A_._auto_wgrad(tuple(maps), dz, wt)
+    torch.cuda.synchronize()
+    assert tuple(dw.shape) == (cout, cin, 1, 1) and tuple(dw3.shape) == (cout, cin, 1, 1)
+    assert relerr(dw.cpu().numpy(), dw_ref) <= 1e-3 and relerr(db.cpu().numpy(), db_ref) <= 1e-3
+    assert relerr(dw.cpu().numpy(), dw3.cpu().numpy()) <= 1e-5 and relerr(db.cpu().numpy(), db3.cpu().numpy()) <= 1e-5
+
+
 def test_wgrad_is_deterministic(F_):
     rng = np.random.default_rng(6)
     x = bf16r(rng.standard_normal((2, 64, 150, 260)))
