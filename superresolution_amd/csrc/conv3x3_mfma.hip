@@ -105,7 +105,7 @@ struct Cfg {
     static constexpr int SLOT_BYTES = sub_bytes(0) + (NSUB == 2 ? sub_bytes(1) : 0);
     static constexpr int NPIECE = SLOT_BYTES / 1024;                // 1 KiB LDS-DMA pieces per row
     static constexpr int MAXP = (NPIECE + NWAVES - 1) / NWAVES;     // pieces per wave per row
-    static constexpr int LA = 5;                                    // rows issued ahead of the row being computed
+    static constexpr int LA = KC_ == 3 ? 4 : 5;                     // rows issued ahead of the row being computed (48-channel rows: one fewer measured faster)
     static constexpr int RING = LA + 1;                             // LDS row slots
     static constexpr int RING_BYTES = RING * SLOT_BYTES;
     // ---- epilogue staging (bf16 NHWC output): the wave's 32 px x (32*NCT) fp32 results cross LDS

@@ -8,7 +8,8 @@ fence right behind its wait, which prints `; srhip-fence <registers>` into the a
 compiles the given .hip files to gfx950 assembly and verifies, on every control-flow path, that between an
 asm load and the fence of its destination registers NO instruction reads or writes those registers (a
 register move there would copy stale data; a re-use would be overwritten when the load lands).  It also checks
-that no VALU instruction overwrites the data registers of a 96/128-bit store directly behind it.
+that no VALU instruction overwrites the data registers of a 96/128-bit store directly behind it, and that no
+compiler-generated instruction touches the destination of an inline-asm MFMA within the MFMA's latency.
 
 usage: isa_lint.py [--keep DIR] file.hip [file.hip ...]      exit status 1 when a violation is found
 """
@@ -28,6 +29,20 @@ FENCE = "; srhip-fence"
 def regs_of(text):
     out = set()
     for m in REG_RE.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+AREG_RE = re.compile(r"\ba(?:(\d+)\b|\[(\d+):(\d+)\])")
+MFMA_WAIT_STATES = 18   # a 32x32 MFMA's result is readable by other instruction types this many wait states after issue
+
+
+def aregs_of(text):
+    out = set()
+    for m in AREG_RE.finditer(text):
         if m.group(1) is not None:
             out.add(int(m.group(1)))
         else:
@@ -146,6 +161,37 @@ def lint_function(name, body):
             if op.startswith("v_") and dst & data:
                 problems.append((i, code, j, c2, sorted(dst & data)))
             break
+    # Third check: the MFMAs are inline asm, so the compiler's hazard recognizer does not know that their result registers
+    # are written many cycles after issue.  A compiler-generated instruction (a v_accvgpr_read / _write it adds when it
+    # splits an accumulator's live range under register pressure) that touches an asm MFMA's destination within the
+    # MFMA's latency reads a stale value or is overwritten.  Dependent asm MFMAs (the accumulation chain) interlock in
+    # hardware and are not flagged; the sources' own reads sit behind enough independent work or an s_nop.
+    mfma_re = re.compile(r"^v_mfma_\w+\s+(a\[\d+:\d+\])")
+    for i, (kind, code, in_asm) in enumerate(insts):
+        if kind != "inst" or not in_asm:
+            continue
+        m = mfma_re.match(code)
+        if not m:
+            continue
+        dst = aregs_of(m.group(1))
+        waited = 0
+        for j in range(i + 1, len(insts)):
+            k2, c2, asm2 = insts[j]
+            if k2 != "inst":
+                continue
+            op = c2.split()[0]
+            if op in ("s_branch", "s_endpgm", "s_barrier") or op.startswith("s_cbranch") or waited >= MFMA_WAIT_STATES:
+                break
+            if op == "s_nop":
+                waited += int(c2.split()[1]) + 1
+                continue
+            if op.startswith("v_mfma"):
+                waited += 8
+                continue
+            if not asm2 and aregs_of(c2) & dst:
+                problems.append((i, code, j, c2, sorted(aregs_of(c2) & dst)))
+                break
+            waited += 1
     return n_loads, problems
 
 
@@ -168,7 +214,7 @@ def lint_file(path, keep=None):
                 continue
             reported.add(key)
             bad += 1
-            print(f"{os.path.basename(path)}: {name[:90]}\n    load  #{i}: {code}\n    touch #{j}: {c2}   (v{regs}) before its fence")
+            print(f"{os.path.basename(path)}: {name[:90]}\n    load  #{i}: {code}\n    touch #{j}: {c2}   ({regs}) too early")
     print(f"{os.path.basename(path)}: {total} asm loads checked, {bad} violation(s)")
     return bad
 
