@@ -148,11 +148,11 @@ def pair_roofline_block(hr_h, hr_w, avg_ms, med_ms, launches):
     px = float(hr_h * hr_w)
     flop, nbytes = 2.0 * px * 64 * 64 * 9 * 2, px * 256.0
     tflops = flop / (avg_ms * 1e-3) / 1e12
-    traffic = measured_traffic_bytes("r2_l_pair_pmc.csv", "conv3x3_pair_kernel<false, 0, false>")
+    traffic = measured_traffic_bytes("r3_bi_pair_pmc.csv", "conv3x3_pair_kernel<false, 0, 0, 0>")
     return {"bound": "mfma", "kernel": f"conv3x3_pair_kernel<false,*> (conv 64->64 + bias + ReLU -> conv 64->64 + bias [+ ReLU], x alpha, + x @ {hr_h}x{hr_w}; "
                                        "9 of the 16 HR launches per frame: 6 SR blocks <false,0> and 3 G-buffer residual pairs <false,1>, timed together)",
             "achieved": tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / BF16_MFMA_PEAK_TFLOPS,
-            "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r2_l_pair_pmc.csv)" if traffic is not None else None,
+            "traffic": traffic, "traffic_unit": "bytes/launch (profiles/r3_bi_pair_pmc.csv)" if traffic is not None else None,
             "avg_launch_ms": avg_ms, "median_launch_ms": med_ms, "launches_timed": launches,
             "algorithmic_bytes_per_launch": nbytes, "algorithmic_flop_per_launch": flop,
             "hbm_view": {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
