@@ -453,7 +453,8 @@ class SuperSampler(nn.Module):
                                                                         warped_buffer.float(), aux_planes=16 if b * f == 1 else 14)
             aux_motion = motion_vectors.reshape(b * f, -1, h, w)
             _rec("pre.marked_frames", marked_frames)
-            _rec("pre.aux", aux_buffer[:, :14].clone())
+            if _TRACE is not None:   # (the copy is for the recorder alone: 29 MB per 544 x 960 frame)
+                _rec("pre.aux", aux_buffer[:, :14].clone())
             _rec("pre.motion", aux_motion)
             _rec("pre.enhance_weight", enhance_weight)
             fmap_history = self.frame_encoder.run(F_.nchw_f32_to_nhwc_bf16(marked_frames))[0]
