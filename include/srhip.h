@@ -343,6 +343,15 @@ SRHIP_API int srhip_relu_mask_bf16(const void* dy, const void* y, void* dst, siz
  * reads two maps and writes one.  bits: srhip_conv3x3_signbits_bytes(n, h, w) bytes. */
 SRHIP_API int srhip_signbits_from_map_bf16(const void* map, void* bits, int n, int h, int w, void* stream);
 SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t count, void* stream);
+/* dst = bf16(a + *scale * y) on bf16 maps of `count` elements, the scalar read from device memory: the G-buffer encoder's
+ * fmap + enhance_param * enhance (core/models/model_final.py:256-258) in the training graph, where enhance_param is a
+ * trained parameter (inference passes its value as the epilogue factor of the last convolution).  fp32 arithmetic, one
+ * rounding.  The backward, one pass over dout and y: dy = bf16(*scale * dout), partials[g] = work-group g's share of
+ * d scale = sum(dout * y) in fp32 (npartials work-groups are launched, each writes its entry; the caller adds them up);
+ * the gradient of a is dout itself. */
+SRHIP_API int srhip_scale_add_bf16(const void* a, const void* y, const float* scale, void* dst, size_t count, void* stream);
+SRHIP_API int srhip_scale_add_bwd_bf16(const void* dout, const void* y, const float* scale, void* dy, float* partials,
+                                       int npartials, size_t count, void* stream);
 
 /* ESA attention helpers of RepRFN (core/arch/RepRFN.py:295-308) on NHWC bf16, c % 8 == 0:
  *   max_pool2d:      F.max_pool2d(x, kernel_size=k, stride=s)  (no padding)       :298

@@ -118,6 +118,8 @@ _SIGNATURES = {
     "srhip_relu_mask_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "srhip_signbits_from_map_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "srhip_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "srhip_scale_add_bf16": (c_int, [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "srhip_scale_add_bwd_bf16": (c_int, [c_void_p] * 5 + [c_int, c_size_t, c_void_p]),
     "srhip_max_pool2d_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "srhip_resize_bilinear_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "srhip_conv_transpose2x2s2": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),

@@ -464,6 +464,28 @@ def attention_fuse(cur: Tensor, fmap: Tensor, grad: Tensor, f_self: Tensor, g_cr
     return _AttentionFuse.apply(cur, fmap, grad, f_self, g_cross, g_self, f_cross)
 
 
+class _ScaleAdd(Function):
+    """bf16(a + scale * y) with a trained 0-d fp32 scale (fmap + enhance_param * enhance, core/models/model_final.py:256-258):
+    one pass forward; backward one pass for dy = bf16(scale * d) and dscale = sum(d * y) in fp32, da = d."""
+
+    @staticmethod
+    def forward(ctx, a, y, scale):
+        ctx.save_for_backward(y, scale)
+        return F_.scale_add_bf16(a, y, scale.detach())
+
+    @staticmethod
+    def backward(ctx, d: Tensor):
+        y, scale = ctx.saved_tensors
+        d = d.contiguous()
+        dy, ds = F_.scale_add_bwd_bf16(d, y, scale.detach())
+        return d, dy, ds.reshape(scale.shape).to(scale.dtype)
+
+
+def scale_add(a: Tensor, y: Tensor, scale: Tensor) -> Tensor:
+    """Differentiable functional.scale_add_bf16: gradients for both maps and for the scale."""
+    return _ScaleAdd.apply(a, y, scale)
+
+
 def conv2d(x, weight: Tensor, bias: Tensor, stride: int = 1, padding: int = 1, act: int = F_.ACT_NONE) -> Tensor:
     """Differentiable functional.conv2d_auto; x is an NHWC bf16 map or a tuple of maps read as their concatenation."""
     srcs = tuple(x) if isinstance(x, (tuple, list)) else (x,)

@@ -548,6 +548,58 @@ __global__ void add_bf16_kernel(const uint4* __restrict__ a, const uint4* __rest
     }
 }
 
+// dst = bf16(a + scale * y) with a trained scalar read from device memory (the G-buffer encoder's
+// fmap + enhance_param * enhance, core/models/model_final.py:256-258, in the training graph): the product and the sum are
+// formed in fp32 and rounded once, as the inference epilogue forms them.
+__global__ void scale_add_bf16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ y, const float* __restrict__ scale,
+                                      uint4* __restrict__ dst, long long nvec)
+{
+    const float p = *scale;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 u = a[i], v = y[i];
+        // (one explicit fma per element, the instruction of the inference epilogues that form the same sum)
+        dst[i] = make_uint4(pack_bf16x2(__fmaf_rn(p, bf16_lo(v.x), bf16_lo(u.x)), __fmaf_rn(p, bf16_hi(v.x), bf16_hi(u.x))),
+                            pack_bf16x2(__fmaf_rn(p, bf16_lo(v.y), bf16_lo(u.y)), __fmaf_rn(p, bf16_hi(v.y), bf16_hi(u.y))),
+                            pack_bf16x2(__fmaf_rn(p, bf16_lo(v.z), bf16_lo(u.z)), __fmaf_rn(p, bf16_hi(v.z), bf16_hi(u.z))),
+                            pack_bf16x2(__fmaf_rn(p, bf16_lo(v.w), bf16_lo(u.w)), __fmaf_rn(p, bf16_hi(v.w), bf16_hi(u.w))));
+    }
+}
+// Its backward in one pass over dout and y: dy = bf16(scale * dout), and the work-group's share of
+// d scale = sum(dout * y) (fp32) in partials[blockIdx.x]; the gradient of a is dout itself.  The grid is fixed by the
+// caller (one partial per work-group), so the sum has one order of additions.
+__global__ __launch_bounds__(kThreads) void scale_add_bwd_bf16_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
+                                                                     const float* __restrict__ scale, uint4* __restrict__ dy,
+                                                                     float* __restrict__ partials, long long nvec)
+{
+    const float p = *scale;
+    float acc = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 g = dout[i], v = y[i];
+        float gf[8], yf[8];
+        gf[0] = bf16_lo(g.x); gf[1] = bf16_hi(g.x); gf[2] = bf16_lo(g.y); gf[3] = bf16_hi(g.y);
+        gf[4] = bf16_lo(g.z); gf[5] = bf16_hi(g.z); gf[6] = bf16_lo(g.w); gf[7] = bf16_hi(g.w);
+        yf[0] = bf16_lo(v.x); yf[1] = bf16_hi(v.x); yf[2] = bf16_lo(v.y); yf[3] = bf16_hi(v.y);
+        yf[4] = bf16_lo(v.z); yf[5] = bf16_hi(v.z); yf[6] = bf16_lo(v.w); yf[7] = bf16_hi(v.w);
+        float part = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += gf[e] * yf[e];
+        acc += part;
+        dy[i] = make_uint4(pack_bf16x2(p * gf[0], p * gf[1]), pack_bf16x2(p * gf[2], p * gf[3]), pack_bf16x2(p * gf[4], p * gf[5]),
+                           pack_bf16x2(p * gf[6], p * gf[7]));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    __shared__ float wsum[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kThreads / 64; ++k) t += wsum[k];
+        partials[blockIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ESA helpers (core/arch/RepRFN.py:295-308) on NHWC bf16: one thread = one output pixel x 8 channels
 // ------------------------------------------------------------------------------------------
@@ -2578,6 +2630,31 @@ SRHIP_API int srhip_add_bf16(const void* a, const void* b, void* dst, size_t cou
     hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint4*)a, (const uint4*)b, (uint4*)dst, nvec);
     return srhip_check_launch("add_bf16");
+}
+
+SRHIP_API int srhip_scale_add_bf16(const void* a, const void* y, const float* scale, void* dst, size_t count, void* stream)
+{
+    SRHIP_REQUIRE(a && y && scale && dst, "scale_add_bf16: null pointer");
+    SRHIP_REQUIRE(count % 8 == 0, "scale_add_bf16: count must be a multiple of 8");
+    SRHIP_REQUIRE((size_t)a % 16 == 0 && (size_t)y % 16 == 0 && (size_t)dst % 16 == 0, "scale_add_bf16: maps must be 16-byte aligned");
+    if (count == 0) return SRHIP_OK;
+    const long long nvec = (long long)(count / 8);
+    hipLaunchKernelGGL(scale_add_bf16_kernel, dim3(grid_for(nvec, srhip_num_cus())), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint4*)a, (const uint4*)y, scale, (uint4*)dst, nvec);
+    return srhip_check_launch("scale_add_bf16");
+}
+
+SRHIP_API int srhip_scale_add_bwd_bf16(const void* dout, const void* y, const float* scale, void* dy, float* partials, int npartials,
+                                       size_t count, void* stream)
+{
+    SRHIP_REQUIRE(dout && y && scale && dy && partials, "scale_add_bwd_bf16: null pointer");
+    SRHIP_REQUIRE(count % 8 == 0, "scale_add_bwd_bf16: count must be a multiple of 8");
+    SRHIP_REQUIRE(npartials >= 1 && npartials <= 65536, "scale_add_bwd_bf16: 1 to 65536 partial sums (got %d)", npartials);
+    SRHIP_REQUIRE((size_t)dout % 16 == 0 && (size_t)y % 16 == 0 && (size_t)dy % 16 == 0, "scale_add_bwd_bf16: maps must be 16-byte aligned");
+    // one partial per work-group, every work-group writes its own (zero when it has no element)
+    hipLaunchKernelGGL(scale_add_bwd_bf16_kernel, dim3(npartials), dim3(kThreads), 0, (hipStream_t)stream, (const uint4*)dout,
+                       (const uint4*)y, scale, (uint4*)dy, partials, (long long)(count / 8));
+    return srhip_check_launch("scale_add_bwd_bf16");
 }
 
 SRHIP_API int srhip_max_pool2d_nhwc(const void* src, void* dst, int n, int c, int h, int w, int k, int s, void* stream)

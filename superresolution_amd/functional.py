@@ -372,6 +372,33 @@ def add_bf16(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = Non
     return out
 
 
+def scale_add_bf16(a: torch.Tensor, y: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """bf16(a + scale * y) with a 0-d fp32 device tensor as the scale (fmap + enhance_param * enhance,
+    core/models/model_final.py:256-258, in the training graph): fp32 arithmetic, one rounding, one pass."""
+    a, y = _req(a, torch.bfloat16, "a"), _req(y, torch.bfloat16, "y")
+    scale = _req(scale.reshape(1), torch.float32, "scale")
+    if a.shape != y.shape:
+        raise ValueError("scale_add_bf16: shapes differ")
+    out = torch.empty_like(a)
+    check(lib.srhip_scale_add_bf16(a.data_ptr(), y.data_ptr(), scale.data_ptr(), out.data_ptr(), a.numel(), _stream()))
+    return out
+
+
+def scale_add_bwd_bf16(dout: torch.Tensor, y: torch.Tensor, scale: torch.Tensor):
+    """Backward of scale_add_bf16 in one pass: returns (dy = bf16(scale * dout), dscale = sum(dout * y), 0-d fp32); the
+    gradient of a is dout itself."""
+    dout, y = _req(dout, torch.bfloat16, "dout"), _req(y, torch.bfloat16, "y")
+    scale = _req(scale.reshape(1), torch.float32, "scale")
+    if dout.shape != y.shape:
+        raise ValueError("scale_add_bwd_bf16: shapes differ")
+    dy = torch.empty_like(y)
+    nparts = max(1, min(2048, (dout.numel() // 8 + 255) // 256))
+    parts = torch.empty(nparts, dtype=torch.float32, device=y.device)
+    check(lib.srhip_scale_add_bwd_bf16(dout.data_ptr(), y.data_ptr(), scale.data_ptr(), dy.data_ptr(), parts.data_ptr(), nparts,
+                                       dout.numel(), _stream()))
+    return dy, parts.sum()
+
+
 def upsample_grid_bilinear_bwd_nhwc(dy: torch.Tensor, sh: int, sw: int, relu_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Backward of upsample_grid_bilinear_nhwc: dy (N,th,tw,C) bf16 -> (N,sh,sw,C) bf16, optionally masked by the
     ReLU output that produced the source."""

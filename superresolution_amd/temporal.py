@@ -228,6 +228,8 @@ class GBuffersEncoder(nn.Module):
             y = _rec(self.conv_enhance[-1], A_.conv2d(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU), last.out_channels)
             # the scale stays fp32 (inference passes float(enhance_param) as the epilogue's alpha and rounds the sum
             # once): the product and the sum are formed in fp32, and enhance_param's gradient is an fp32 reduction
+            if self.enhance_param.dtype == torch.float32 and fmap.shape == y.shape and os.environ.get("SRHIP_NO_SCALE_ADD", "0") != "1":
+                return _rec("buffers_encoder.out", A_.scale_add(fmap, y, self.enhance_param), fmap.shape[-1]), vmax   # the same, one pass
             return _rec("buffers_encoder.out", (fmap.float() + self.enhance_param * y.float()).to(torch.bfloat16), fmap.shape[-1]), vmax
         # fmap + enhance_param * relu(conv(e)): scale and add ride on the last convolution's epilogue
         return F_.conv2d_auto(e, last.weight, last.bias, stride=1, padding=0, act=F_.ACT_RELU,

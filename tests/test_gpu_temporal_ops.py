@@ -446,3 +446,27 @@ def test_zero_insert2_places_the_gradient_at_the_even_positions(F_, case):
     ref[:, ::2, ::2] = x
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+def test_scale_add_and_its_backward_vs_torch(F_):
+    """bf16(a + scale * y) with a trained scalar (fmap + enhance_param * enhance, core/models/model_final.py:256-258) as one
+    pass, and its one-pass backward, against the torch expression it replaces in the training graph: the forward within
+    one bf16 step (fma against multiply-then-add), da bit for bit, dy within a bf16 step, dscale to 1e-4 relative; an
+    element count that does not fill the last work-group."""
+    from superresolution_amd import autograd_ops as A
+    torch.manual_seed(5)
+    for shape in ((2, 37, 41, 64), (1, 8, 8, 16)):
+        a = torch.randn(shape, device="cuda").to(torch.bfloat16).requires_grad_(True)
+        y = torch.randn(shape, device="cuda").to(torch.bfloat16).requires_grad_(True)
+        p = torch.tensor(0.45, device="cuda", requires_grad=True)
+        d = torch.randn(shape, device="cuda").to(torch.bfloat16)
+        out = A.scale_add(a, y, p)
+        out.backward(d)
+        a2, y2, p2 = (t.detach().clone().requires_grad_(True) for t in (a, y, p))
+        ref = (a2.float() + p2 * y2.float()).to(torch.bfloat16)
+        ref.backward(d)
+        step = lambda t: t.float().abs().clamp_min(1e-3) * 2.0 ** -7
+        assert bool(((out.float() - ref.float()).abs() <= step(ref)).all())
+        assert torch.equal(a.grad, a2.grad)
+        assert bool(((y.grad.float() - y2.grad.float()).abs() <= step(y2.grad)).all())
+        assert abs(float(p.grad) - float(p2.grad)) <= 1e-4 * max(1.0, abs(float(p2.grad)))
