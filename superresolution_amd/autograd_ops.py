@@ -341,6 +341,13 @@ def _dgrad_rows(dzs: Tensor, w: Tensor, row0: int, rows: int, mask: Tensor = Non
         wp = F_.conv_gemm_pack_weights_transposed(w, row0, rows, cpad)
         return F_.conv_gemm(dzs, wp, None, rows, k, stride=1, padding=k // 2, res=mask,
                             res_mode=F_.RES_MASK if mask is not None else F_.RES_ADD)
+    if k == 3 and cpad <= 64 and rows <= 64 and cpad % 16 == 0 and w.dtype == torch.float32 and w.is_contiguous() \
+            and cpad - w.shape[0] < 16 and (mask is None or mask.shape[-1] == F_.pad16(rows)) \
+            and os.environ.get("SRHIP_NO_PACK_T", "0") != "1":
+        # one launch of the register-resident kernel: its packer reads the stored weights transposed and flipped (no flip /
+        # copy launches in front of it)
+        wp = F_.conv3x3_pack_weights(w, w.shape[0], cpad, cout=rows, cout_off=row0, transpose_flip=True)
+        return F_.conv3x3(dzs, wp, None, rows, res=mask, res_mode=F_.RES_MASK if mask is not None else F_.RES_ADD)
     wt = (w.transpose(0, 1).flip(2, 3) if k == 3 else w.transpose(0, 1))[row0:row0 + rows].contiguous()
     if mask is None:
         return F_.conv2d_auto(dzs, wt, None, stride=1, padding=k // 2)        # (N,h,w,pad16(rows))

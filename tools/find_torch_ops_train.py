@@ -8,6 +8,7 @@ from torch.utils._python_dispatch import TorchDispatchMode
 from superresolution_amd.temporal import SuperSampler
 from superresolution_amd.loss import enhance_weighted_l1
 
+MIN_BYTES = int(float(sys.argv[1])) if len(sys.argv) > 1 else (1 << 20)   # smallest tensor that makes an operator count
 sites = collections.Counter()
 nbytes = collections.Counter()
 
@@ -20,7 +21,7 @@ class Spy(TorchDispatchMode):
         for t in list(args) + [out]:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 big = max(big, t.numel() * t.element_size())
-        if big >= (1 << 20) and not any(k in name for k in ("view", "reshape", "detach", "alias", "as_strided", "permute", "slice", "select", "transpose", "unsqueeze", "expand", "_unsafe_view", "t.default", "empty", "split", "unbind", "squeeze", "narrow")):
+        if big >= MIN_BYTES and not any(k in name for k in ("view", "reshape", "detach", "alias", "as_strided", "permute", "slice", "select", "transpose", "unsqueeze", "expand", "_unsafe_view", "t.default", "empty", "split", "unbind", "squeeze", "narrow")):
             st = [f for f in traceback.extract_stack() if "superresolution_amd" in f.filename]
             key = (name, tuple(f"{os.path.basename(f.filename)}:{f.lineno}" for f in st[-3:]))
             sites[key] += 1
@@ -52,5 +53,6 @@ step(); step()
 with Spy():
     step()
 torch.cuda.synchronize()
-for key, n in sorted(sites.items(), key=lambda kv: -nbytes[kv[0]])[:60]:
+for key, n in sorted(sites.items(), key=lambda kv: -nbytes[kv[0]])[:int(os.environ.get('TOP', '60'))]:
     print(f"{nbytes[key] / 1e6:9.1f} MB {n:3d}x {key[0]:40s} " + " <- ".join(key[1]))
+print(sum(sites.values()), "operators")
