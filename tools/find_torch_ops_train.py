@@ -30,23 +30,36 @@ class Spy(TorchDispatchMode):
 
 
 dev = torch.device("cuda")
+WHICH = os.environ.get("MODEL", "temporal")   # temporal | reprfn
 B, S, SCALE = 16, 256, 4
 torch.manual_seed(42)
-model = SuperSampler(3, 10, SCALE, 1).to(dev).train()
 g = torch.Generator().manual_seed(42)
-ins = [torch.rand(B, 3, S, S, generator=g), torch.rand(B, 10, S * SCALE, S * SCALE, generator=g), torch.rand(B, 10, S, S, generator=g),
-       torch.randn(B, 1, 2, S, S, generator=g), torch.rand(B, 1, 3, S, S, generator=g), torch.rand(B, 1, 10, S, S, generator=g)]
-ins = [t.to(dev) for t in ins]
-target = torch.rand(B, 3, S * SCALE, S * SCALE, generator=g).to(dev)
+if WHICH == "reprfn":
+    from superresolution_amd import RepRFN
+    model = RepRFN().to(dev).train()
+    x = torch.rand(B, 3, S // SCALE, S // SCALE, generator=g).to(dev)
+    target = torch.rand(B, 3, S, S, generator=g).to(dev)
 
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = (model(x) - target).abs().mean()
+        loss.backward()
+        return loss
+else:
+    model = SuperSampler(3, 10, SCALE, 1).to(dev).train()
+    ins = [torch.rand(B, 3, S, S, generator=g), torch.rand(B, 10, S * SCALE, S * SCALE, generator=g), torch.rand(B, 10, S, S, generator=g),
+           torch.randn(B, 1, 2, S, S, generator=g), torch.rand(B, 1, 3, S, S, generator=g), torch.rand(B, 1, 10, S, S, generator=g)]
+    ins = [t.to(dev) for t in ins]
+    target = torch.rand(B, 3, S * SCALE, S * SCALE, generator=g).to(dev)
 
-def step():
-    for p in model.parameters():
-        p.grad = None
-    sr, ew = model(*ins)
-    loss = enhance_weighted_l1(sr, target, ew)
-    loss.backward()
-    return loss
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        sr, ew = model(*ins)
+        loss = enhance_weighted_l1(sr, target, ew)
+        loss.backward()
+        return loss
 
 
 step(); step()
