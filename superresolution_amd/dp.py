@@ -129,16 +129,18 @@ class FlatGradAllReducer:
             self._launch(b)
 
     def _collect_bucket(self, b: int) -> None:
-        src, dst = [], []
+        src, dst, empty = [], [], []
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             if self.bucket_of[i] != b or p.grad is v:
                 continue
             if p.grad is None:
-                v.zero_()
+                empty.append(v)
             else:
                 src.append(p.grad)
                 dst.append(v)
             p.grad = v
+        if empty:
+            torch._foreach_zero_(empty)
         if src:
             torch._foreach_copy_(dst, src)
 
@@ -231,16 +233,18 @@ class FlatGradAllReducer:
 
     def collect(self) -> None:
         """Gather mode: move the gradients backward produced into the buffer (parameters without one get zeros)."""
-        src, dst = [], []
+        src, dst, empty = [], [], []
         for p, v in zip(self.params, self.views):
             if p.grad is v:
                 continue
             if p.grad is None:
-                v.zero_()
+                empty.append(v)
             else:
                 src.append(p.grad)
                 dst.append(v)
             p.grad = v
+        if empty:
+            torch._foreach_zero_(empty)   # one launch for all of them (RepRFN's training form has dozens)
         if src:
             torch._foreach_copy_(dst, src)
 

@@ -18,7 +18,10 @@ class Spy(TorchDispatchMode):
         out = func(*args, **(kwargs or {}))
         name = str(func)
         big = 0
+        flat = []
         for t in list(args) + [out]:
+            flat.extend(t if isinstance(t, (list, tuple)) else [t])
+        for t in flat:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 big = max(big, t.numel() * t.element_size())
         if big >= MIN_BYTES and not any(k in name for k in ("view", "reshape", "detach", "alias", "as_strided", "permute", "slice", "select", "transpose", "unsqueeze", "expand", "_unsafe_view", "t.default", "empty", "split", "unbind", "squeeze", "narrow")):
@@ -61,6 +64,25 @@ else:
         loss.backward()
         return loss
 
+
+if os.environ.get("FULL", "0") == "1":   # the whole training step of bench.py: bucketed reducer and fused AdamW around it
+    from superresolution_amd.dp import FlatGradAllReducer
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = FlatGradAllReducer(params, gather=True, buckets=2 if WHICH == "reprfn" else 4).attach_hooks()
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)
+    inner = step
+
+    def step():
+        red.zero_grad()
+        if WHICH == "reprfn":
+            loss = (model(x) - target).abs().mean()
+        else:
+            sr, ew = model(*ins)
+            loss = enhance_weighted_l1(sr, target, ew)
+        loss.backward()
+        red.all_reduce()
+        opt.step()
+        return loss
 
 step(); step()
 with Spy():
