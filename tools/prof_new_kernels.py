@@ -3,7 +3,7 @@
     rocprofv3 --pmc <counters> -- python3 tools/prof_new_kernels.py <case>
 cases: chain (160-160-160-64 1x1 chain at 544x960), chain_res (112-64-64-64 + residual), esa (ESA tail at 540x960 x 48),
 loss (fused clip + L1 + SSIM forward and backward at 16 x 3 x 1024 x 1024), upbwd (x4 up-sampling backward at 16 x 1024 x 1024 x 32),
-ln (channels-first LayerNorm forward + backward at 540 x 960 x 64 fp32), warp16 (bf16 NHWC warp of a 4K 16-channel frame, smooth motion),
+ln (channels-first LayerNorm forward + backward at 540 x 960 x 64 fp32), scaleadd (a + scale * y and its backward at 16 x 256 x 256 x 64), warp16 (bf16 NHWC warp of a 4K 16-channel frame, smooth motion),
 pairbwd (both data gradients of an SRResidualBlock at 16 x 1024 x 1024), pairbits (the forward launch that emits the bits)."""
 import os
 import sys
@@ -41,6 +41,12 @@ elif case == "ln":
     for _ in range(REP):
         F_.layernorm_cf(x, w, b, 1e-6)
         F_.layernorm_cf_bwd(x, w, dy)
+elif case == "scaleadd":
+    a, y, d = (rnd(16, 256, 256, 64).to(torch.bfloat16) for _ in range(3))
+    p = torch.tensor(0.45, device=dev)
+    for _ in range(REP):
+        F_.scale_add_bf16(a, y, p)
+        F_.scale_add_bwd_bf16(d, y, p)
 elif case == "warp16":
     fr = rnd(1, 2160, 3840, 16).to(torch.bfloat16)
     mv = torch.nn.functional.interpolate(torch.randn(1, 2, 28, 48, device=dev) * 4, size=(2160, 3840), mode="bilinear", align_corners=True)
